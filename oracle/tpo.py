@@ -1,0 +1,350 @@
+"""ctypes binding of the CPU ORACLE (oracle/libtp_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py. The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KTINY = 2.220446049250313e-16 * 1e5
+KMAXSD2 = 1e6
+
+OK = 0
+ERR_NAMES = {
+    0: "ok", 2: "infeasible_bounds", 3: "s_range", 4: "sd_start_neg",
+    5: "lower_ge_upper", 6: "too_few_samples", 7: "no_connection",
+    8: "nan_sd2", 9: "nonzero_end", 10: "crit_index_zero", 11: "not_solved",
+}
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libtp_oracle.so")
+    src = os.path.join(_HERE, "tp_oracle.c")
+    hdr = os.path.join(_HERE, "tp_oracle.h")
+    if force or not os.path.exists(so) or any(
+            os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "libtp_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = build()
+    L = C.CDLL(so)
+    d, i, vp = C.c_double, C.c_int, C.c_void_p
+    L.tpo_knot_span.restype = i
+    L.tpo_knot_span.argtypes = [_dp, i, i, d]
+    L.tpo_basis.argtypes = [_dp, i, i, d, _dp]
+    L.tpo_basis_and_derivatives.argtypes = [_dp, i, i, i, d, _dp]
+    L.tpo_eval_curve.restype = i
+    L.tpo_eval_curve.argtypes = [_dp, i, i, _dp, i, d, _dp]
+    L.tpo_eval_curve_and_derivatives.restype = i
+    L.tpo_eval_curve_and_derivatives.argtypes = [_dp, i, i, _dp, i, d, i, _dp]
+    L.tpo_make_uniform_knots.restype = i
+    L.tpo_make_uniform_knots.argtypes = [i, i, d, d, _dp]
+    L.tpo_polyline_to_bspline3_waypoints.restype = i
+    L.tpo_polyline_to_bspline3_waypoints.argtypes = [_dp, i, i, d, _dp]
+    L.tpo_joint_fit_spline.restype = i
+    L.tpo_joint_fit_spline.argtypes = [_dp, i, i, d, _dp, _dp]
+    L.tpo_joint_sample_path.restype = i
+    L.tpo_joint_sample_path.argtypes = [_dp, i, _dp, i, i, d, d, i, _dp, _dp, _dp]
+    L.tpo_joint_constraint_setup.argtypes = [_dp, _dp, i, i, _dp, _dp, d, _dp, _dp, _dp, _dp]
+    L.tpo_cartesian_path_derivatives.argtypes = [_dp, i, i, d, _dp, _dp]
+    L.tpo_cartesian_constraint_setup.argtypes = [_dp, _dp, _dp, i, i, _dp, _dp, d, d, d,
+                                                 _dp, _dp, _dp, _dp]
+    L.tpo_profile_create.restype = vp
+    L.tpo_profile_create.argtypes = [i, i]
+    L.tpo_profile_destroy.argtypes = [vp]
+    L.tpo_profile_set_max_loops.argtypes = [vp, i]
+    L.tpo_profile_setup.restype = i
+    L.tpo_profile_setup.argtypes = [vp, _dp, _dp, _dp, _dp, d, d, d, d, d]
+    L.tpo_profile_optimize.restype = i
+    L.tpo_profile_optimize.argtypes = [vp]
+    L.tpo_profile_calculate_boundary.restype = i
+    L.tpo_profile_calculate_boundary.argtypes = [vp]
+    for name in ("time", "s", "sd", "sdd", "sd2", "sd2_max", "sdd_max_for_sd2_max",
+                 "sdd_min_for_sd2_max", "sd2_max_for_sdd0"):
+        f = getattr(L, "tpo_profile_" + name)
+        f.restype = C.POINTER(d)
+        f.argtypes = [vp]
+    L.tpo_profile_boundary_type.restype = C.POINTER(C.c_uint8)
+    L.tpo_profile_boundary_type.argtypes = [vp]
+    L.tpo_profile_last_extremal_index.restype = i
+    L.tpo_profile_last_extremal_index.argtypes = [vp]
+    L.tpo_profile_max_time_increment.restype = d
+    L.tpo_profile_max_time_increment.argtypes = [vp]
+    L.tpo_profile_num_loops_used.restype = i
+    L.tpo_profile_num_loops_used.argtypes = [vp]
+    L.tpo_profile_constraint_violations.restype = i
+    L.tpo_profile_constraint_violations.argtypes = [vp]
+    L.tpo_profile_query.restype = i
+    L.tpo_profile_query.argtypes = [vp, d, C.POINTER(d), C.POINTER(d), C.POINTER(d)]
+    L.tpo_profile_previous_index.restype = i
+    L.tpo_profile_previous_index.argtypes = [vp, d]
+    for name in ("simplex", "bruteforce"):
+        f = getattr(L, "tpo_find_max_sd2_" + name)
+        f.argtypes = [_dp, _dp, _dp, _dp, i, C.POINTER(d), C.POINTER(d), C.POINTER(d)]
+    for name in ("max", "min"):
+        f = getattr(L, "tpo_find_sdd_" + name)
+        f.restype = d
+        f.argtypes = [_dp, _dp, _dp, _dp, i, d]
+    L.tpo_epilogue.argtypes = [_dp, _dp, i, i, _dp, _dp, _dp, _dp, _dp]
+    L.tpo_resample_uniform.restype = i
+    L.tpo_resample_uniform.argtypes = [_dp] * 7 + [i, i, d, d, _dp, i] + [_dp] * 7
+    L.tpo_resample_uniform_count.restype = i
+    L.tpo_resample_uniform_count.argtypes = [d, d, d]
+    L.tpo_time_joint_path.restype = i
+    L.tpo_time_joint_path.argtypes = [_dp, i, _dp, i, i, _dp, _dp, d, d, d, i, d, d, d, vp,
+                                      _dp, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(i)]
+    L.tpo_time_joint_batch.restype = i
+    L.tpo_time_joint_batch.argtypes = [i, _dp, i, _dp, i, i, _dp, _dp, d, _dp, _dp, i, _dp, _dp,
+                                       i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    _LIB = L
+    return L
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# ------------------------------------------------------------------ splines
+def knot_span(knots, degree, u):
+    k = _f64(knots)
+    return lib().tpo_knot_span(k, len(k), degree, float(u))
+
+
+def basis(knots, span, p, u):
+    out = np.zeros(p + 1)
+    lib().tpo_basis(_f64(knots), span, p, float(u), out)
+    return out
+
+
+def basis_and_derivatives(knots, span, p, der, u):
+    out = np.zeros((der + 1, p + 1))
+    lib().tpo_basis_and_derivatives(_f64(knots), span, p, der, float(u), out)
+    return out
+
+
+def eval_curve(knots, degree, points, u):
+    k, pts = _f64(knots), _f64(points)
+    out = np.zeros(pts.shape[1])
+    rc = lib().tpo_eval_curve(k, len(k), degree, pts, pts.shape[1], float(u), out)
+    return rc, out
+
+
+def eval_curve_and_derivatives(knots, degree, points, u, nvalues):
+    k, pts = _f64(knots), _f64(points)
+    out = np.zeros((nvalues, pts.shape[1]))
+    rc = lib().tpo_eval_curve_and_derivatives(k, len(k), degree, pts, pts.shape[1],
+                                              float(u), nvalues, out)
+    return rc, out
+
+
+def make_uniform_knots(num_points, degree, low=0.0, high=1.0):
+    out = np.zeros(num_points + degree + 1)
+    rc = lib().tpo_make_uniform_knots(num_points, degree, low, high, out)
+    return rc, out
+
+
+def polyline_to_bspline3_waypoints(corners, radius):
+    c = _f64(corners)
+    W, D = c.shape
+    out = np.zeros((max(3 * W - 2, 4), D))
+    n = lib().tpo_polyline_to_bspline3_waypoints(c, W, D, float(radius), out)
+    return out[:n]
+
+
+def joint_fit_spline(waypoints, rounding=0.2):
+    w = _f64(waypoints)
+    W, D = w.shape
+    P = 3 * W - 2 if W > 1 else 4
+    cps = np.zeros((P, D))
+    knots = np.zeros(P + 3)
+    lib().tpo_joint_fit_spline(w, W, D, float(rounding), cps, knots)
+    return cps, knots
+
+
+def joint_sample_path(knots, cps, path_start, delta, N):
+    k, c = _f64(knots), _f64(cps)
+    P, D = c.shape
+    q, q1, q2 = np.zeros((N, D)), np.zeros((N, D)), np.zeros((N, D))
+    rc = lib().tpo_joint_sample_path(k, len(k), c, P, D, float(path_start), float(delta),
+                                     N, q, q1, q2)
+    assert rc == 0, rc
+    return q, q1, q2
+
+
+def joint_constraint_setup(q1, q2, vmax, amax, safety=0.8):
+    q1, q2 = _f64(q1), _f64(q2)
+    N, D = q1.shape
+    A, B, lo, hi = (np.zeros((N, 2 * D)) for _ in range(4))
+    lib().tpo_joint_constraint_setup(q1, q2, N, D, _f64(vmax), _f64(amax), float(safety),
+                                     A, B, lo, hi)
+    return A, B, lo, hi
+
+
+def cartesian_path_derivatives(q, delta):
+    q = _f64(q)
+    N, D = q.shape
+    q1, q2 = np.zeros((N, D)), np.zeros((N, D))
+    lib().tpo_cartesian_path_derivatives(q, N, D, float(delta), q1, q2)
+    return q1, q2
+
+
+def cartesian_constraint_setup(q1, q2, jq1, vmax, amax, vtrans, vrot, safety=0.8):
+    q1, q2, jq1 = _f64(q1), _f64(q2), _f64(jq1)
+    N, D = q1.shape
+    A, B, lo, hi = (np.zeros((N, 2 * D + 2)) for _ in range(4))
+    lib().tpo_cartesian_constraint_setup(q1, q2, jq1, N, D, _f64(vmax), _f64(amax),
+                                         float(vtrans), float(vrot), float(safety),
+                                         A, B, lo, hi)
+    return A, B, lo, hi
+
+
+# ------------------------------------------------------------------- solver
+class Profile:
+    """Mirror of TimeOptimalPathProfile on the oracle."""
+
+    def __init__(self, N, Cn):
+        self.N, self.C = N, Cn
+        self._p = lib().tpo_profile_create(N, Cn)
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            lib().tpo_profile_destroy(self._p)
+            self._p = None
+
+    def set_max_loops(self, n):
+        lib().tpo_profile_set_max_loops(self._p, int(n))
+
+    def setup(self, A, B, lo, hi, s_start, s_end, sd_start=0.0, sdd_start=0.0, t_start=0.0):
+        return lib().tpo_profile_setup(self._p, _f64(A), _f64(B), _f64(lo), _f64(hi),
+                                       s_start, s_end, sd_start, sdd_start, t_start)
+
+    def optimize(self):
+        return lib().tpo_profile_optimize(self._p)
+
+    def calculate_boundary(self):
+        return lib().tpo_profile_calculate_boundary(self._p)
+
+    def _arr(self, name):
+        ptr = getattr(lib(), "tpo_profile_" + name)(self._p)
+        return np.ctypeslib.as_array(ptr, shape=(self.N,)).copy()
+
+    time = property(lambda self: self._arr("time"))
+    s = property(lambda self: self._arr("s"))
+    sd = property(lambda self: self._arr("sd"))
+    sdd = property(lambda self: self._arr("sdd"))
+    sd2 = property(lambda self: self._arr("sd2"))
+    sd2_max = property(lambda self: self._arr("sd2_max"))
+    sdd_max_for_sd2_max = property(lambda self: self._arr("sdd_max_for_sd2_max"))
+    sdd_min_for_sd2_max = property(lambda self: self._arr("sdd_min_for_sd2_max"))
+    sd2_max_for_sdd0 = property(lambda self: self._arr("sd2_max_for_sdd0"))
+
+    @property
+    def boundary_type(self):
+        ptr = lib().tpo_profile_boundary_type(self._p)
+        return np.ctypeslib.as_array(ptr, shape=(self.N,)).copy()
+
+    @property
+    def last_extremal_index(self):
+        return lib().tpo_profile_last_extremal_index(self._p)
+
+    @property
+    def max_time_increment(self):
+        return lib().tpo_profile_max_time_increment(self._p)
+
+    @property
+    def loops_used(self):
+        return lib().tpo_profile_num_loops_used(self._p)
+
+    def constraint_violations(self):
+        return lib().tpo_profile_constraint_violations(self._p)
+
+    def query(self, t):
+        s, sd, sdd = C.c_double(), C.c_double(), C.c_double()
+        ok = lib().tpo_profile_query(self._p, float(t), C.byref(s), C.byref(sd), C.byref(sdd))
+        return bool(ok), s.value, sd.value, sdd.value
+
+    def previous_index(self, t):
+        return lib().tpo_profile_previous_index(self._p, float(t))
+
+
+def _lp(fn, A, B, lo, hi):
+    A, B, lo, hi = _f64(A), _f64(B), _f64(lo), _f64(hi)
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    fn(A, B, lo, hi, len(A), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def find_max_sd2_simplex(A, B, lo, hi):
+    return _lp(lib().tpo_find_max_sd2_simplex, A, B, lo, hi)
+
+
+def find_max_sd2_bruteforce(A, B, lo, hi):
+    return _lp(lib().tpo_find_max_sd2_bruteforce, A, B, lo, hi)
+
+
+def find_sdd_max(A, B, lo, hi, sd2):
+    A = _f64(A)
+    return lib().tpo_find_sdd_max(A, _f64(B), _f64(lo), _f64(hi), len(A), float(sd2))
+
+
+def find_sdd_min(A, B, lo, hi, sd2):
+    A = _f64(A)
+    return lib().tpo_find_sdd_min(A, _f64(B), _f64(lo), _f64(hi), len(A), float(sd2))
+
+
+# ------------------------------------------------------- epilogue / resample
+def epilogue(q1, q2, sd, sdd, amax):
+    q1, q2 = _f64(q1), _f64(q2)
+    N, D = q1.shape
+    qd, qdd = np.zeros((N, D)), np.zeros((N, D))
+    lib().tpo_epilogue(q1, q2, N, D, _f64(sd), _f64(sdd), _f64(amax), qd, qdd)
+    return qd, qdd
+
+
+def resample_uniform(t, s, sd, sdd, q, qd, qdd, start_sec, time_step, amax):
+    q = _f64(q)
+    N, D = q.shape
+    M = lib().tpo_resample_uniform_count(float(t[-1]), float(start_sec), float(time_step))
+    ot, os_, osd, osdd = (np.zeros(M) for _ in range(4))
+    oq, oqd, oqdd = (np.zeros((M, D)) for _ in range(3))
+    lib().tpo_resample_uniform(_f64(t), _f64(s), _f64(sd), _f64(sdd), q, _f64(qd), _f64(qdd),
+                               N, D, float(start_sec), float(time_step), _f64(amax), M,
+                               ot, os_, osd, osdd, oq, oqd, oqdd)
+    return ot, os_, osd, osdd, oq, oqd, oqdd
+
+
+# ------------------------------------------------------------ whole hot path
+def time_joint_batch(knots, cps, vmax, amax, path_start, delta, N, sd_start=None,
+                     time_start=None, safety=0.8, nthreads=1):
+    """knots [B][K], cps [B][P][D], vmax/amax [B][D], path_start/delta [B]."""
+    knots, cps = _f64(knots), _f64(cps)
+    B, K = knots.shape
+    _, P, D = cps.shape
+    path_start = _f64(np.broadcast_to(path_start, (B,)))
+    delta = _f64(np.broadcast_to(delta, (B,)))
+    sd_start = _f64(np.zeros(B) if sd_start is None else np.broadcast_to(sd_start, (B,)))
+    time_start = _f64(np.zeros(B) if time_start is None else np.broadcast_to(time_start, (B,)))
+    t, s, sd, sdd = (np.zeros((B, N)) for _ in range(4))
+    q, qd, qdd = (np.zeros((B, N, D)) for _ in range(3))
+    lei = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    lib().tpo_time_joint_batch(B, knots, K, cps, P, D, _f64(vmax), _f64(amax), float(safety),
+                               path_start, delta, N, sd_start, time_start, int(nthreads),
+                               t, s, sd, sdd, q, qd, qdd, lei, status)
+    return dict(t=t, s=s, sd=sd, sdd=sdd, q=q, qd=qd, qdd=qdd,
+                last_extremal_index=lei, status=status)

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Mine the numeric fixtures the reference's own tests hold for the hot path.
+
+Runs ONLY in the build container (reads /root/reference as text; nothing of the
+reference is imported, compiled or executed). It writes DATA (numbers) into
+tests/golden/*.json; no reference source text is stored.
+
+Fixtures extracted:
+  * bspline_golden.json   - the eight 101-value Mathematica tables of
+    trajectory_planning/splines/bspline_test.cc (kGoldenDataX .. Yppp) plus the
+    inputs of BSplineGoldenTest.CompareToReference (:737-753) restated as data.
+  * lp_regression.json    - the five literal 30-row LPs of
+    trajectory_planning/time_optimal_path_timing_test.cc (:758-1072).
+"""
+import json
+import os
+import re
+import sys
+
+REF = "/root/reference/trajectory_planning"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+NUM = r"[-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)"
+
+
+def numbers(text):
+    return [float(x) for x in re.findall(NUM, text)]
+
+
+def extract_bspline_tables():
+    src = open(os.path.join(REF, "splines", "bspline_test.cc")).read()
+    tables = {}
+    for name in ["X", "Y", "Xp", "Yp", "Xpp", "Ypp", "Xppp", "Yppp"]:
+        m = re.search(
+            r"kGoldenData%s\[GetNumSamples\(\)\]\s*=\s*\{(.*?)\};" % name, src, re.S)
+        assert m, name
+        vals = numbers(m.group(1))
+        assert len(vals) == 101, (name, len(vals))
+        tables[name] = vals
+    fixture = {
+        "source": "trajectory_planning/splines/bspline_test.cc:97-726 (tables), :737-753 (inputs)",
+        "degree": 3,
+        "knots": [0, 0, 0, 0, 0.5, 1, 1, 1, 1],
+        "control_points": [[1, 1], [2, 3], [3, -1], [4, 1], [5, 0]],
+        "num_samples": 101,
+        "tolerance_error_norm": 5e-14,
+        "tables": tables,
+    }
+    with open(os.path.join(OUT, "bspline_golden.json"), "w") as f:
+        json.dump(fixture, f)
+    print("bspline_golden.json: 8 tables x 101 values")
+
+
+def extract_lp_regression():
+    src = open(os.path.join(REF, "time_optimal_path_timing_test.cc")).read()
+    start = src.index("std::vector<LPInfo> lpinfo")
+    end = src.index("for (", start)
+    body = src[start:end]
+    # each case: {30, {a...}, {b...}, {lower...}, {upper...}}
+    cases = []
+    pos = body.index("{") + 1
+    # walk brace structure
+    depth = 0
+    cur = None
+    groups = []
+    i = pos
+    while i < len(body):
+        ch = body[i]
+        if ch == "{":
+            depth += 1
+            if depth == 1:
+                cur_start = i
+                groups = []
+            elif depth == 2:
+                grp_start = i
+        elif ch == "}":
+            if depth == 2:
+                groups.append(numbers(body[grp_start + 1:i]))
+            elif depth == 1:
+                head = body[cur_start + 1:body.index("{", cur_start + 1)]
+                sz = int(numbers(head)[0])
+                assert len(groups) == 4 and all(len(g) == sz for g in groups), (
+                    sz, [len(g) for g in groups])
+                cases.append({"size": sz, "a": groups[0], "b": groups[1],
+                              "lower": groups[2], "upper": groups[3]})
+            elif depth == 0:
+                break
+            depth -= 1
+        i += 1
+    assert len(cases) == 5, len(cases)
+    fixture = {
+        "source": "trajectory_planning/time_optimal_path_timing_test.cc:758-1072",
+        "expected": "FindMaxSd2Simplex == FindMaxSd2BruteForce within 1e-8 (:1083-1086)",
+        "cases": cases,
+    }
+    with open(os.path.join(OUT, "lp_regression.json"), "w") as f:
+        json.dump(fixture, f)
+    print("lp_regression.json: %d cases" % len(cases))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference tree not present; fixtures are already committed")
+    os.makedirs(OUT, exist_ok=True)
+    extract_bspline_tables()
+    extract_lp_regression()
