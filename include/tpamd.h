@@ -1,0 +1,223 @@
+/*
+ * tpamd.h -- C-ABI of the MI355X (gfx950) batched time-optimal path-timing engine.
+ *
+ * The reference (theteamatx/x-edr-trajectory-planning) has no FFI: its boundary
+ * is the C++ class API of trajectory_planning/. Every entry point below names
+ * the reference interface (file:line under trajectory_planning/) whose work it
+ * performs for a BATCH of independent paths. The C++ mirror classes in
+ * x-edr-trajectory-planning_amd/host/ call these with B = 1 (drop-in) or B >> 1
+ * (BatchPathTiming); INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *  - All arithmetic is fp64 (time_optimal_path_timing.h:38-41).
+ *  - "_device" entry points take DEVICE pointers, enqueue work on the given HIP
+ *    stream (hipStream_t passed as void*) and return without synchronising.
+ *    "_host" entry points take HOST pointers, copy in, run, copy out and
+ *    synchronise before returning.
+ *  - Return value: 0 on success, a negative TPAMD_E_* code for call-level errors
+ *    (bad arguments, HIP failure). Per-path solver outcomes are written to the
+ *    status[] array (TPAMD_PATH_*), in the reference's order of checks.
+ *  - No exceptions cross this boundary. An engine handle is not thread-safe;
+ *    distinct engines may be used from distinct threads.
+ */
+#ifndef TPAMD_H_
+#define TPAMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPAMD_VERSION 100
+
+/* call-level errors */
+#define TPAMD_E_INVALID_ARGUMENT (-1)
+#define TPAMD_E_HIP (-2)
+#define TPAMD_E_UNSUPPORTED (-3)
+#define TPAMD_E_NO_DEVICE (-4)
+
+/* per-path status (status[b]); 0 = solved. Codes follow the reference's checks:
+ * SetupProblem (time_optimal_path_timing.cc:165-193), IsSetupValid (:554-576),
+ * OptimizePathParameter (:383-391, :400-403, :422-428). */
+#define TPAMD_PATH_OK 0
+#define TPAMD_PATH_INFEASIBLE_BOUNDS 2
+#define TPAMD_PATH_S_RANGE 3
+#define TPAMD_PATH_SD_START_NEGATIVE 4
+#define TPAMD_PATH_LOWER_GE_UPPER 5
+#define TPAMD_PATH_TOO_FEW_SAMPLES 6
+#define TPAMD_PATH_NO_CONNECTION 7
+#define TPAMD_PATH_NAN_SD2 8
+#define TPAMD_PATH_NONZERO_END 9
+#define TPAMD_PATH_CRIT_INDEX_ZERO 10 /* reference reads sd2_max[-1] here (.cc:361,:372) */
+
+typedef struct tpamd_engine tpamd_engine;
+
+/* Engine lifetime. An engine owns a device workspace that grows on demand
+ * (outside any timed region once warmed up) and is bound to one HIP device. */
+int tpamd_engine_create(int device_ordinal, tpamd_engine **out);
+void tpamd_engine_destroy(tpamd_engine *engine);
+int tpamd_version(void);
+const char *tpamd_error_string(int code);
+/* Pre-size the workspace for batches up to (num_paths, num_samples, num_rows). */
+int tpamd_engine_reserve(tpamd_engine *engine, int num_paths, int num_samples,
+                         int num_rows);
+/* Bytes of device workspace currently held. */
+size_t tpamd_engine_workspace_bytes(const tpamd_engine *engine);
+
+/* ------------------------------------------------------------------------
+ * Form (i): joint-space degree-2 B-spline paths.
+ * Performs, per path, what PathTimingTrajectory::ComputeTimingProfile runs for a
+ * TimeableJointSplinePath (path_timing_trajectory.cc:307-475):
+ *   SamplePath          timeable_path_joint_spline.cc:294-318
+ *                       (BSplineBase::KnotSpan bspline_base.cc:218-246,
+ *                        UpdateBasisAndDerivatives :268-348,
+ *                        BSplineT::EvalCurveAndDerivatives bspline.h:540-568)
+ *   ConstraintSetup     timeable_path_joint_spline.cc:320-343 (C = 2D rows)
+ *   InitSolver/SetupProblem/SetSetupDone  time_optimal_path_timing.cc:135-203,:535-576
+ *                       with s_start = path_start, s_end = path_start + delta*(N-1)
+ *   OptimizePathParameter                  time_optimal_path_timing.cc:287-490
+ *   epilogue qd = q'*sd, qdd = clamp(q'*sdd + q''*sd^2, +-a_max)  path_timing_trajectory.cc:458-472
+ * ------------------------------------------------------------------------ */
+typedef struct tpamd_joint_batch {
+  int32_t num_paths;        /* B */
+  int32_t num_dofs;         /* D, 1..16 */
+  int32_t num_samples;      /* N, 3..8192 (JointPathOptions::num_path_samples) */
+  int32_t num_points;       /* P control points per path; P+3 knots */
+  int32_t max_solver_loops; /* <=0: max(100, 10*N) as path_timing_trajectory.cc:398-400 */
+  int32_t reserved;
+  double constraint_safety; /* PathOptions::constraint_safety, timeable_path.h:80 */
+} tpamd_joint_batch;
+
+typedef struct tpamd_joint_inputs {
+  const double *knots;          /* [B][P+3] */
+  const double *control_points; /* [B][P][D] */
+  const double *max_velocity;   /* [B][D]  TimeablePath::SetMaxJointVelocity */
+  const double *max_acceleration; /* [B][D] TimeablePath::SetMaxJointAcceleration */
+  const double *path_start;     /* [B]  SamplePath(path_start) */
+  const double *delta;          /* [B]  PathOptions::delta_parameter */
+  const double *sd_start;       /* [B]  SetupProblem sd_start */
+  const double *sdd_start;      /* [B]  SetupProblem sdd_start; NULL = 0 */
+  const double *time_start;     /* [B]  SetupProblem time_start */
+} tpamd_joint_inputs;
+
+typedef struct tpamd_path_outputs {
+  double *time;  /* [B][N] GetTimeSamples()      */
+  double *s;     /* [B][N] GetPathParameter()    */
+  double *sd;    /* [B][N] GetPathVelocity()     */
+  double *sdd;   /* [B][N] GetPathAcceleration() */
+  double *q;     /* [B][N][D] GetPathPositionAt(i); may be NULL */
+  double *qd;    /* [B][N][D] velocity_at_path_samples_; may be NULL */
+  double *qdd;   /* [B][N][D] acceleration_at_path_samples_; may be NULL */
+  int32_t *last_extremal_index; /* [B] GetLastExtremalIndex(); may be NULL */
+  double *max_time_increment;   /* [B] GetMaxTimeIncrement(); may be NULL */
+  int32_t *status;              /* [B] TPAMD_PATH_* */
+} tpamd_path_outputs;
+
+int tpamd_time_joint_paths_device(tpamd_engine *engine, const tpamd_joint_batch *batch,
+                                  const tpamd_joint_inputs *in,
+                                  const tpamd_path_outputs *out, void *hip_stream);
+int tpamd_time_joint_paths_host(tpamd_engine *engine, const tpamd_joint_batch *batch,
+                                const tpamd_joint_inputs *in,
+                                const tpamd_path_outputs *out);
+
+/* ------------------------------------------------------------------------
+ * Form (ii): explicit constraint rows  lower <= A*sdd + B*sd^2 <= upper.
+ * Batched TimeOptimalPathProfile::InitSolver + SetupProblem +
+ * OptimizePathParameter (time_optimal_path_timing.h:118-150). Row arrays are
+ * [B][N][C] (sample-major, row-minor): Constraint::a_coefficient/b_coefficient/
+ * lower/upper (time_optimal_path_timing.h:65-102). q/qd/qdd outputs are unused.
+ * ------------------------------------------------------------------------ */
+typedef struct tpamd_rows_batch {
+  int32_t num_paths;        /* B */
+  int32_t num_samples;      /* N */
+  int32_t num_rows;         /* C, 1..64 */
+  int32_t max_solver_loops; /* <=0: 100 (time_optimal_path_timing.h:339) */
+} tpamd_rows_batch;
+
+typedef struct tpamd_rows_inputs {
+  const double *a;      /* [B][N][C] */
+  const double *b;      /* [B][N][C] */
+  const double *lower;  /* [B][N][C] */
+  const double *upper;  /* [B][N][C] */
+  const double *s_start, *s_end, *sd_start, *sdd_start, *time_start; /* [B] each */
+} tpamd_rows_inputs;
+
+int tpamd_optimize_rows_device(tpamd_engine *engine, const tpamd_rows_batch *batch,
+                               const tpamd_rows_inputs *in,
+                               const tpamd_path_outputs *out, void *hip_stream);
+int tpamd_optimize_rows_host(tpamd_engine *engine, const tpamd_rows_batch *batch,
+                             const tpamd_rows_inputs *in,
+                             const tpamd_path_outputs *out);
+
+/* Batched TimeOptimalPathProfile::FindMaxSd2Simplex (time_optimal_path_timing.cc:1149-1363)
+ * on num_lps independent constraint sets of C rows each ([num_lps][C] arrays);
+ * outputs sd2max/sddmax/sd2zero [num_lps]. Host pointers. */
+int tpamd_find_max_sd2_host(tpamd_engine *engine, int num_lps, int num_rows,
+                            const double *a, const double *b, const double *lower,
+                            const double *upper, double *sd2max, double *sddmax,
+                            double *sd2zero);
+
+/* ------------------------------------------------------------------------
+ * s(t) query: batched TimeOptimalPathProfile::GetPathParameterAndDerivatives
+ * (time_optimal_path_timing.cc:1549-1627) on solved profiles. For each path b
+ * and query k: t_query[b][k] -> s, sd, sdd, ok [B][K]. time/s/sd are the [B][N]
+ * outputs of the LAST solve on this engine (its squared velocities sd2_ and the
+ * per-path ds, s_start, s_end are still held in the engine workspace, so call
+ * this before the next solve). status may be NULL. Device pointers.
+ * ------------------------------------------------------------------------ */
+int tpamd_query_device(tpamd_engine *engine, int num_paths, int num_samples,
+                       int num_queries, const double *time, const double *s,
+                       const double *sd, const int32_t *status, const double *t_query,
+                       double *out_s, double *out_sd, double *out_sdd, int32_t *ok,
+                       void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Uniform-in-time resample: PathTimingTrajectory::ResampleEquidistantlyInTime
+ * (path_timing_trajectory.cc:755-783) with InterpolateAtTime (:709-753) for a
+ * batch of solved paths. Output row b holds count[b] = ceil((t_end-start)/dt)+1
+ * samples, written at [b][0..count) of arrays with stride max_out; if
+ * count[b] > max_out only max_out samples are written (count still reports the
+ * full number). Device pointers.
+ * ------------------------------------------------------------------------ */
+typedef struct tpamd_resample_args {
+  int32_t num_paths, num_samples, num_dofs, max_out;
+  const double *time, *s, *sd, *sdd; /* [B][N] */
+  const double *q, *qd, *qdd;        /* [B][N][D] */
+  const double *max_acceleration;    /* [B][D] */
+  const double *start_sec;           /* [B] */
+  double time_step;
+  const int32_t *status;             /* [B] paths with status != 0 are skipped; may be NULL */
+  double *out_time, *out_s, *out_sd, *out_sdd; /* [B][max_out] */
+  double *out_q, *out_qd, *out_qdd;            /* [B][max_out][D] */
+  int32_t *count;                              /* [B] */
+} tpamd_resample_args;
+
+int tpamd_resample_uniform_device(tpamd_engine *engine, const tpamd_resample_args *args,
+                                  void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Debug/inspection: copy the boundary curve of the LAST solve to host arrays
+ * [B][N] (Boundary::sd2_max, sdd_max_for_sd2_max, sdd_min_for_sd2_max,
+ * sd2_max_for_sdd0, type; time_optimal_path_timing.h:225-255) and the squared
+ * velocity sd2_. Any pointer may be NULL. Synchronises the device.
+ * ------------------------------------------------------------------------ */
+int tpamd_debug_copy_boundary(tpamd_engine *engine, int num_paths, int num_samples,
+                              double *sd2_max, double *sdd_max, double *sdd_min,
+                              double *sd2_zero, uint8_t *type, double *sd2);
+
+/* Name and average-launch bookkeeping of the dominant kernel for bench.py:
+ * records HIP events around the sweep kernel of every solve on its own stream.
+ * Returns the mean duration in milliseconds over the launches since the last
+ * reset (0 if none). */
+void tpamd_profile_reset(tpamd_engine *engine);
+void tpamd_profile_enable(tpamd_engine *engine, int enable);
+double tpamd_profile_mean_ms(tpamd_engine *engine, int kernel_index, int *num_launches);
+const char *tpamd_profile_kernel_name(int kernel_index);
+int tpamd_profile_num_kernels(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPAMD_H_ */

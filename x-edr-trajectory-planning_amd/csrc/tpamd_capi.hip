@@ -1,0 +1,582 @@
+// tpamd_capi.hip -- C-ABI of the engine (include/tpamd.h): workspace, launches,
+// host-buffer convenience paths and per-kernel event timing.
+#include "../../include/tpamd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "tpamd_kernels.h"
+
+using namespace tpamd;
+
+namespace {
+
+enum KernelIndex { KI_SETUP = 0, KI_SAMPLE_LP, KI_DETECT, KI_FINAL, KI_SWEEP, KI_EPILOGUE, KI_COUNT };
+const char *kKernelNames[KI_COUNT] = {"k_setup", "k_sample_lp", "k_boundary_detect",
+                                      "k_boundary_final", "k_sweep", "k_epilogue"};
+
+struct EventPair {
+  hipEvent_t start, stop;
+  int kernel;
+};
+
+#define HIPCHK(expr)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      std::fprintf(stderr, "[tpamd] HIP error %s at %s:%d: %s\n", #expr, __FILE__, \
+                   __LINE__, hipGetErrorString(e_));                              \
+      return TPAMD_E_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// bump allocator over the staging buffer (first pass with base == null only sizes)
+struct Stage {
+  char *base;
+  size_t off = 0;
+  explicit Stage(void *b) : base((char *)b) {}
+  template <typename T>
+  T *take(size_t count) {
+    T *p = base ? (T *)(base + off) : nullptr;
+    off = align_up(off + count * sizeof(T), 256);
+    return p;
+  }
+};
+
+}  // namespace
+
+struct tpamd_engine {
+  int device = 0;
+  void *ws_base = nullptr;
+  size_t ws_bytes = 0;
+  void *stage_base = nullptr;  // staging for the _host entry points
+  size_t stage_bytes = 0;
+  Workspace ws{};
+  int last_B = 0, last_N = 0;
+  bool profile = false;
+  std::vector<EventPair> events;
+};
+
+namespace {
+
+// Carve the workspace for (B, N, C). Returns the bytes needed; fills ws when base != null.
+size_t carve_workspace(char *base, int B, int N, int C, Workspace *ws) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) -> char * {
+    char *p = base ? base + off : nullptr;
+    off = align_up(off + bytes, 256);
+    return p;
+  };
+  const size_t nb = (size_t)B, ns = (size_t)B * N;
+  Workspace w{};
+  w.ds = (double *)take(nb * 8);
+  w.s_start = (double *)take(nb * 8);
+  w.s_end = (double *)take(nb * 8);
+  w.sd_start = (double *)take(nb * 8);
+  w.sdd_start = (double *)take(nb * 8);
+  w.t_start = (double *)take(nb * 8);
+  w.delta = (double *)take(nb * 8);
+  w.err_bits = (uint32_t *)take(nb * 4);
+  w.lim = (double *)take(nb * 2 * C * 8);
+  w.q12 = (double *)take(ns * C * 8);
+  w.m0 = (double *)take(ns * 8);
+  w.z0 = (double *)take(ns * 8);
+  w.X0 = (double *)take(ns * 8);
+  w.Y0 = (double *)take(ns * 8);
+  w.Xz = (double *)take(ns * 8);
+  w.Yz = (double *)take(ns * 8);
+  w.at0 = (uint8_t *)take(ns);
+  w.fix_flag = (uint8_t *)take(ns);
+  w.fix_val = (double *)take(ns * 8);
+  w.m = (double *)take(ns * 8);
+  w.X = (double *)take(ns * 8);
+  w.Y = (double *)take(ns * 8);
+  w.type = (uint8_t *)take(ns);
+  w.sd2 = (double *)take(ns * 8);
+  if (ws) *ws = w;
+  return off;
+}
+
+int ensure_workspace(tpamd_engine *e, int B, int N, int C) {
+  const size_t need = carve_workspace(nullptr, B, N, C, nullptr);
+  if (need > e->ws_bytes) {
+    if (e->ws_base) HIPCHK(hipFree(e->ws_base));
+    e->ws_base = nullptr;
+    e->ws_bytes = 0;
+    HIPCHK(hipMalloc(&e->ws_base, need));
+    e->ws_bytes = need;
+  }
+  carve_workspace((char *)e->ws_base, B, N, C, &e->ws);
+  return 0;
+}
+
+int ensure_stage(tpamd_engine *e, size_t need) {
+  if (need > e->stage_bytes) {
+    if (e->stage_base) HIPCHK(hipFree(e->stage_base));
+    e->stage_base = nullptr;
+    e->stage_bytes = 0;
+    HIPCHK(hipMalloc(&e->stage_base, need));
+    e->stage_bytes = need;
+  }
+  return 0;
+}
+
+struct Timer {
+  tpamd_engine *e;
+  hipStream_t st;
+  int kernel;
+  EventPair ev{};
+  bool on;
+  Timer(tpamd_engine *e_, hipStream_t st_, int k) : e(e_), st(st_), kernel(k), on(e_->profile) {
+    if (on) {
+      (void)hipEventCreate(&ev.start);
+      (void)hipEventCreate(&ev.stop);
+      ev.kernel = kernel;
+      (void)hipEventRecord(ev.start, st);
+    }
+  }
+  ~Timer() {
+    if (on) {
+      (void)hipEventRecord(ev.stop, st);
+      e->events.push_back(ev);
+    }
+  }
+};
+
+int lds_limit_set = 0;
+
+template <typename K>
+void allow_big_lds(K kernel) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void configure_kernels_once() {
+  if (lds_limit_set) return;
+  lds_limit_set = 1;
+  allow_big_lds(k_sample_lp_joint<1>);
+  allow_big_lds(k_lp_rows<1>);
+  allow_big_lds(k_lp_rows<2>);
+  allow_big_lds(k_sweep<JointSource>);
+  allow_big_lds(k_sweep<GenericSource>);
+}
+
+// Shared tail: detect -> final -> sweep (-> epilogue in joint mode).
+template <class Source>
+int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int max_loops,
+                           const Source &src, const tpamd_path_outputs *out) {
+  const Workspace &ws = e->ws;
+  const dim3 grid_s((N + 255) / 256, B);
+  {
+    Timer t(e, st, KI_DETECT);
+    hipLaunchKernelGGL(k_boundary_detect, grid_s, dim3(256), 0, st, N, ws);
+  }
+  {
+    Timer t(e, st, KI_FINAL);
+    hipLaunchKernelGGL((k_boundary_final<Source>), grid_s, dim3(256), 0, st, N, src, ws);
+  }
+  {
+    Timer t(e, st, KI_SWEEP);
+    const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
+    hipLaunchKernelGGL((k_sweep<Source>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
+                       out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
+                       out->max_time_increment, out->status);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tpamd_version(void) { return TPAMD_VERSION; }
+
+const char *tpamd_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case TPAMD_E_INVALID_ARGUMENT: return "invalid argument";
+    case TPAMD_E_HIP: return "HIP runtime error";
+    case TPAMD_E_UNSUPPORTED: return "unsupported size";
+    case TPAMD_E_NO_DEVICE: return "no HIP device";
+    case TPAMD_PATH_INFEASIBLE_BOUNDS: return "infeasible bounds: no upper > lower at a sample";
+    case TPAMD_PATH_S_RANGE: return "s_start must be < s_end";
+    case TPAMD_PATH_SD_START_NEGATIVE: return "sd_start must be >= 0";
+    case TPAMD_PATH_LOWER_GE_UPPER: return "constraints must satisfy lower < upper";
+    case TPAMD_PATH_TOO_FEW_SAMPLES: return "need at least 2 samples";
+    case TPAMD_PATH_NO_CONNECTION: return "could not connect from critical point to initial trajectory portion";
+    case TPAMD_PATH_NAN_SD2: return "no solution found (NaN in sd2)";
+    case TPAMD_PATH_NONZERO_END: return "non-zero terminal velocity";
+    case TPAMD_PATH_CRIT_INDEX_ZERO: return "critical point search degenerated to index 0";
+    default: return "unknown";
+  }
+}
+
+int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
+  if (!out) return TPAMD_E_INVALID_ARGUMENT;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    std::fprintf(stderr, "[tpamd] no HIP device available: the engine has no CPU fallback\n");
+    return TPAMD_E_NO_DEVICE;
+  }
+  if (device_ordinal < 0 || device_ordinal >= count) return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(device_ordinal));
+  tpamd_engine *e = new (std::nothrow) tpamd_engine();
+  if (!e) return TPAMD_E_HIP;
+  e->device = device_ordinal;
+  configure_kernels_once();
+  *out = e;
+  return 0;
+}
+
+void tpamd_engine_destroy(tpamd_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (auto &ev : e->events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
+  if (e->ws_base) (void)hipFree(e->ws_base);
+  if (e->stage_base) (void)hipFree(e->stage_base);
+  delete e;
+}
+
+int tpamd_engine_reserve(tpamd_engine *e, int B, int N, int C) {
+  if (!e || B <= 0 || N <= 0 || C <= 0) return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  return ensure_workspace(e, B, N, C);
+}
+
+size_t tpamd_engine_workspace_bytes(const tpamd_engine *e) { return e ? e->ws_bytes : 0; }
+
+int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
+                                  const tpamd_joint_inputs *in, const tpamd_path_outputs *out,
+                                  void *hip_stream) {
+  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+  const int B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples, P = bt->num_points;
+  if (B <= 0) return B == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (D < 1 || D > 16 || N < 3 || N > 8192 || P < 3) return TPAMD_E_UNSUPPORTED;
+  if (!in->knots || !in->control_points || !in->max_velocity || !in->max_acceleration ||
+      !in->path_start || !in->delta || !in->sd_start || !in->time_start || !out->time ||
+      !out->s || !out->sd || !out->sdd || !out->status)
+    return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int C = 2 * D;
+  int rc = ensure_workspace(e, B, N, C);
+  if (rc) return rc;
+  e->last_B = B; e->last_N = N;
+  const Workspace &ws = e->ws;
+  const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : std::max(100, 10 * N);
+  {
+    Timer t(e, st, KI_SETUP);
+    hipLaunchKernelGGL(k_setup_joint, dim3((B + 127) / 128), dim3(128), 0, st, B, N, D,
+                       bt->constraint_safety, in->max_velocity, in->max_acceleration,
+                       in->path_start, in->delta, in->sd_start, in->sdd_start, in->time_start,
+                       ws);
+  }
+  {
+    Timer t(e, st, KI_SAMPLE_LP);
+    const int tpb = (C <= 14) ? 256 : (C <= 28 ? 128 : 64);
+    const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)C * tpb) * 8;
+    if (lds > 160 * 1024) return TPAMD_E_UNSUPPORTED;
+    hipLaunchKernelGGL((k_sample_lp_joint<1>), dim3((N + tpb - 1) / tpb, B), dim3(tpb), lds, st,
+                       N, D, P, in->knots, in->control_points, out->q, ws);
+  }
+  JointSource src;
+  src.q12 = ws.q12; src.lim = ws.lim; src.D = D;
+  rc = run_boundary_and_sweep(e, st, B, N, max_loops, src, out);
+  if (rc) return rc;
+  if (out->qd || out->qdd) {
+    Timer t(e, st, KI_EPILOGUE);
+    const size_t total = (size_t)B * N;
+    hipLaunchKernelGGL(k_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, N,
+                       D, ws.q12, out->sd, out->sdd, in->max_acceleration, out->status, out->qd,
+                       out->qdd);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tpamd_optimize_rows_device(tpamd_engine *e, const tpamd_rows_batch *bt,
+                               const tpamd_rows_inputs *in, const tpamd_path_outputs *out,
+                               void *hip_stream) {
+  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+  const int B = bt->num_paths, N = bt->num_samples, C = bt->num_rows;
+  if (B <= 0) return B == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (C < 1 || C > 64 || N < 3 || N > 8192) return TPAMD_E_UNSUPPORTED;
+  if (!in->a || !in->b || !in->lower || !in->upper || !in->s_start || !in->s_end ||
+      !in->sd_start || !in->time_start || !out->time || !out->s || !out->sd || !out->sdd ||
+      !out->status)
+    return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  int rc = ensure_workspace(e, B, N, 1);
+  if (rc) return rc;
+  e->last_B = B; e->last_N = N;
+  const Workspace &ws = e->ws;
+  const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 100;
+  {
+    Timer t(e, st, KI_SETUP);
+    hipLaunchKernelGGL(k_setup_rows, dim3((B + 127) / 128), dim3(128), 0, st, B, N, in->s_start,
+                       in->s_end, in->sd_start, in->sdd_start, in->time_start, ws);
+  }
+  {
+    Timer t(e, st, KI_SAMPLE_LP);
+    const int tpb = 64;
+    const size_t lds = 4 * (size_t)C * tpb * 8;
+    const dim3 grid((N + tpb - 1) / tpb, B);
+    if (C <= 32)
+      hipLaunchKernelGGL((k_lp_rows<1>), grid, dim3(tpb), lds, st, N, C, in->a, in->b, in->lower,
+                         in->upper, ws);
+    else
+      hipLaunchKernelGGL((k_lp_rows<2>), grid, dim3(tpb), lds, st, N, C, in->a, in->b, in->lower,
+                         in->upper, ws);
+  }
+  GenericSource src;
+  src.A = in->a; src.B = in->b; src.LO = in->lower; src.HI = in->upper; src.C = C;
+  return run_boundary_and_sweep(e, st, B, N, max_loops, src, out);
+}
+
+// ---- host-buffer convenience paths ---------------------------------------
+
+int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
+                                const tpamd_joint_inputs *in, const tpamd_path_outputs *out) {
+  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples, P = bt->num_points;
+  if (bt->num_paths <= 0) return bt->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_knots = s.take<double>(B * (P + 3)), *d_cp = s.take<double>(B * P * D);
+    double *d_vmax = s.take<double>(B * D), *d_amax = s.take<double>(B * D);
+    double *d_ps = s.take<double>(B), *d_dl = s.take<double>(B), *d_sd0 = s.take<double>(B);
+    double *d_sdd0 = s.take<double>(B), *d_t0 = s.take<double>(B);
+    double *d_t = s.take<double>(B * N), *d_s = s.take<double>(B * N);
+    double *d_sd = s.take<double>(B * N), *d_sdd = s.take<double>(B * N);
+    double *d_q = out->q ? s.take<double>(B * N * D) : nullptr;
+    double *d_qd = out->qd ? s.take<double>(B * N * D) : nullptr;
+    double *d_qdd = out->qdd ? s.take<double>(B * N * D) : nullptr;
+    int32_t *d_lei = s.take<int32_t>(B), *d_st = s.take<int32_t>(B);
+    double *d_dtm = s.take<double>(B);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(d_knots, in->knots, B * (P + 3) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cp, in->control_points, B * P * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_vmax, in->max_velocity, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_amax, in->max_acceleration, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ps, in->path_start, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_dl, in->delta, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sd0, in->sd_start, B * 8, hipMemcpyHostToDevice, st));
+    if (in->sdd_start)
+      HIPCHK(hipMemcpyAsync(d_sdd0, in->sdd_start, B * 8, hipMemcpyHostToDevice, st));
+    else
+      HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
+    HIPCHK(hipMemcpyAsync(d_t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
+    tpamd_joint_inputs din{d_knots, d_cp, d_vmax, d_amax, d_ps, d_dl, d_sd0, d_sdd0, d_t0};
+    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, d_q, d_qd, d_qdd, d_lei, d_dtm, d_st};
+    int rc = tpamd_time_joint_paths_device(e, bt, &din, &dout, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out->time, d_t, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->s, d_s, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->sd, d_sd, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->sdd, d_sdd, B * N * 8, hipMemcpyDeviceToHost, st));
+    if (out->q) HIPCHK(hipMemcpyAsync(out->q, d_q, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    if (out->qd) HIPCHK(hipMemcpyAsync(out->qd, d_qd, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    if (out->qdd) HIPCHK(hipMemcpyAsync(out->qdd, d_qdd, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    if (out->last_extremal_index)
+      HIPCHK(hipMemcpyAsync(out->last_extremal_index, d_lei, B * 4, hipMemcpyDeviceToHost, st));
+    if (out->max_time_increment)
+      HIPCHK(hipMemcpyAsync(out->max_time_increment, d_dtm, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->status, d_st, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+int tpamd_optimize_rows_host(tpamd_engine *e, const tpamd_rows_batch *bt,
+                             const tpamd_rows_inputs *in, const tpamd_path_outputs *out) {
+  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = bt->num_paths, N = bt->num_samples, C = bt->num_rows;
+  if (bt->num_paths <= 0) return bt->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_a = s.take<double>(B * N * C), *d_b = s.take<double>(B * N * C);
+    double *d_lo = s.take<double>(B * N * C), *d_hi = s.take<double>(B * N * C);
+    double *d_s0 = s.take<double>(B), *d_s1 = s.take<double>(B), *d_sd0 = s.take<double>(B);
+    double *d_sdd0 = s.take<double>(B), *d_t0 = s.take<double>(B);
+    double *d_t = s.take<double>(B * N), *d_s = s.take<double>(B * N);
+    double *d_sd = s.take<double>(B * N), *d_sdd = s.take<double>(B * N);
+    int32_t *d_lei = s.take<int32_t>(B), *d_st = s.take<int32_t>(B);
+    double *d_dtm = s.take<double>(B);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(d_a, in->a, B * N * C * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_b, in->b, B * N * C * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_lo, in->lower, B * N * C * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_hi, in->upper, B * N * C * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_s0, in->s_start, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_s1, in->s_end, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sd0, in->sd_start, B * 8, hipMemcpyHostToDevice, st));
+    if (in->sdd_start)
+      HIPCHK(hipMemcpyAsync(d_sdd0, in->sdd_start, B * 8, hipMemcpyHostToDevice, st));
+    else
+      HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
+    HIPCHK(hipMemcpyAsync(d_t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
+    tpamd_rows_inputs din{d_a, d_b, d_lo, d_hi, d_s0, d_s1, d_sd0, d_sdd0, d_t0};
+    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, nullptr, nullptr, nullptr, d_lei, d_dtm, d_st};
+    int rc = tpamd_optimize_rows_device(e, bt, &din, &dout, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out->time, d_t, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->s, d_s, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->sd, d_sd, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->sdd, d_sdd, B * N * 8, hipMemcpyDeviceToHost, st));
+    if (out->last_extremal_index)
+      HIPCHK(hipMemcpyAsync(out->last_extremal_index, d_lei, B * 4, hipMemcpyDeviceToHost, st));
+    if (out->max_time_increment)
+      HIPCHK(hipMemcpyAsync(out->max_time_increment, d_dtm, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->status, d_st, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+int tpamd_find_max_sd2_host(tpamd_engine *e, int num, int C, const double *a, const double *b,
+                            const double *lower, const double *upper, double *sd2max,
+                            double *sddmax, double *sd2zero) {
+  if (!e || num < 0 || !a || !b || !lower || !upper || !sd2max || !sddmax || !sd2zero)
+    return TPAMD_E_INVALID_ARGUMENT;
+  if (num == 0) return 0;
+  if (C < 1 || C > 64) return TPAMD_E_UNSUPPORTED;
+  HIPCHK(hipSetDevice(e->device));
+  const size_t n = (size_t)num, nc = n * C;
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_a = s.take<double>(nc), *d_b = s.take<double>(nc), *d_lo = s.take<double>(nc),
+           *d_hi = s.take<double>(nc);
+    double *d_o0 = s.take<double>(n), *d_o1 = s.take<double>(n), *d_o2 = s.take<double>(n);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(d_a, a, nc * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_b, b, nc * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_lo, lower, nc * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_hi, upper, nc * 8, hipMemcpyHostToDevice, st));
+    const dim3 grid((num + 63) / 64);
+    if (C <= 32)
+      hipLaunchKernelGGL((k_lp_only<1>), grid, dim3(64), 0, st, num, C, d_a, d_b, d_lo, d_hi, d_o0,
+                         d_o1, d_o2);
+    else
+      hipLaunchKernelGGL((k_lp_only<2>), grid, dim3(64), 0, st, num, C, d_a, d_b, d_lo, d_hi, d_o0,
+                         d_o1, d_o2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sd2max, d_o0, n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(sddmax, d_o1, n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(sd2zero, d_o2, n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+int tpamd_query_device(tpamd_engine *e, int B, int N, int K, const double *time, const double *s,
+                       const double *sd, const int32_t *status, const double *t_query,
+                       double *os, double *osd, double *osdd, int32_t *ok, void *hip_stream) {
+  if (!e || !time || !s || !sd || !t_query || !os || !osd || !osdd) return TPAMD_E_INVALID_ARGUMENT;
+  if (B != e->last_B || N != e->last_N) return TPAMD_E_INVALID_ARGUMENT;
+  if (B <= 0 || K <= 0) return 0;
+  HIPCHK(hipSetDevice(e->device));
+  const size_t total = (size_t)B * K;
+  hipLaunchKernelGGL(k_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)hip_stream, B, N, K, time, s, sd, status, e->ws, t_query, os,
+                     osd, osdd, ok);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tpamd_resample_uniform_device(tpamd_engine *e, const tpamd_resample_args *a,
+                                  void *hip_stream) {
+  if (!e || !a) return TPAMD_E_INVALID_ARGUMENT;
+  if (a->num_paths <= 0) return a->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (a->num_samples < 2 || a->num_dofs < 1 || a->max_out < 1 || !(a->time_step > 0))
+    return TPAMD_E_INVALID_ARGUMENT;
+  if (!a->time || !a->s || !a->sd || !a->sdd || !a->q || !a->qd || !a->qdd ||
+      !a->max_acceleration || !a->start_sec || !a->out_time || !a->out_s || !a->out_sd ||
+      !a->out_sdd || !a->out_q || !a->out_qd || !a->out_qdd || !a->count)
+    return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  ResampleParams p;
+  p.B = a->num_paths; p.N = a->num_samples; p.D = a->num_dofs; p.max_out = a->max_out;
+  p.time = a->time; p.s = a->s; p.sd = a->sd; p.sdd = a->sdd;
+  p.q = a->q; p.qd = a->qd; p.qdd = a->qdd; p.amax = a->max_acceleration;
+  p.start_sec = a->start_sec; p.time_step = a->time_step; p.status = a->status;
+  p.ot = a->out_time; p.os = a->out_s; p.osd = a->out_sd; p.osdd = a->out_sdd;
+  p.oq = a->out_q; p.oqd = a->out_qd; p.oqdd = a->out_qdd; p.count = a->count;
+  hipLaunchKernelGGL(k_resample, dim3((a->max_out + 255) / 256, a->num_paths), dim3(256), 0,
+                     (hipStream_t)hip_stream, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tpamd_debug_copy_boundary(tpamd_engine *e, int B, int N, double *sd2_max, double *sdd_max,
+                              double *sdd_min, double *sd2_zero, uint8_t *type, double *sd2) {
+  if (!e || B != e->last_B || N != e->last_N) return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = (size_t)B * N;
+  if (sd2_max) HIPCHK(hipMemcpy(sd2_max, e->ws.m, n * 8, hipMemcpyDeviceToHost));
+  if (sdd_max) HIPCHK(hipMemcpy(sdd_max, e->ws.X, n * 8, hipMemcpyDeviceToHost));
+  if (sdd_min) HIPCHK(hipMemcpy(sdd_min, e->ws.Y, n * 8, hipMemcpyDeviceToHost));
+  if (sd2_zero) HIPCHK(hipMemcpy(sd2_zero, e->ws.z0, n * 8, hipMemcpyDeviceToHost));
+  if (type) HIPCHK(hipMemcpy(type, e->ws.type, n, hipMemcpyDeviceToHost));
+  if (sd2) HIPCHK(hipMemcpy(sd2, e->ws.sd2, n * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+void tpamd_profile_enable(tpamd_engine *e, int enable) {
+  if (e) e->profile = enable != 0;
+}
+
+void tpamd_profile_reset(tpamd_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  for (auto &ev : e->events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
+  e->events.clear();
+}
+
+double tpamd_profile_mean_ms(tpamd_engine *e, int kernel_index, int *num_launches) {
+  if (num_launches) *num_launches = 0;
+  if (!e) return 0.0;
+  (void)hipSetDevice(e->device);
+  double total = 0.0;
+  int n = 0;
+  for (auto &ev : e->events) {
+    if (ev.kernel != kernel_index) continue;
+    if (hipEventSynchronize(ev.stop) != hipSuccess) continue;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) { total += ms; n++; }
+  }
+  if (num_launches) *num_launches = n;
+  return n ? total / n : 0.0;
+}
+
+const char *tpamd_profile_kernel_name(int k) { return (k >= 0 && k < KI_COUNT) ? kKernelNames[k] : ""; }
+int tpamd_profile_num_kernels(void) { return KI_COUNT; }
+
+}  // extern "C"

@@ -1,0 +1,455 @@
+// tpamd_device.h -- device-side building blocks (gfx950, fp64, no FMA contraction).
+//
+// Everything here keeps the reference's floating-point operation order, because
+// comparisons against kTiny decide control flow in the solver
+// (trajectory_planning/time_optimal_path_timing.cc:778,:799,:805). Build with
+// -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+namespace tpamd {
+
+// time_optimal_path_timing.h:275-279
+constexpr double kTiny = 2.220446049250313e-16 * 1e5;
+constexpr double kMaxSd2 = 1e6;
+
+// Boundary classification, time_optimal_path_timing.h:226-231
+enum : uint8_t { kBndNone = 0, kBndSource = 1, kBndSink = 2, kBndTrajectory = 4 };
+
+// setup error bits (resolved to TPAMD_PATH_* in the reference's order of checks)
+enum : uint32_t {
+  kErrInfeasible = 1u,    // .cc:174-182
+  kErrSRange = 2u,        // .cc:185
+  kErrSdStartNeg = 4u,    // .cc:190
+  kErrLowerGeUpper = 8u,  // .cc:557
+  kErrTooFew = 16u        // .cc:568
+};
+
+__device__ __forceinline__ bool is_tiny(double v) { return fabs(v) < kTiny; }
+__device__ __forceinline__ double qnan() { return __longlong_as_double(0x7ff8000000000000LL); }
+
+__device__ __forceinline__ int status_from_bits(uint32_t bits) {
+  if (bits & kErrInfeasible) return 2;
+  if (bits & kErrSRange) return 3;
+  if (bits & kErrSdStartNeg) return 4;
+  if (bits & kErrLowerGeUpper) return 5;
+  if (bits & kErrTooFew) return 6;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Row accessors. A "row set" is the C constraint rows of ONE path sample:
+//   lower(c) <= a(c)*sdd + b(c)*sd2 <= upper(c)
+// (TimeOptimalPathProfile::Constraint, time_optimal_path_timing.h:65-102).
+// ---------------------------------------------------------------------------
+
+// Rows of this thread's sample staged in LDS, column-strided ([c][thread]).
+struct LdsRows {
+  const double *A, *B, *LO, *HI;  // already offset by the thread index
+  int stride;                     // threads per block
+  int lim_stride;                 // stride of LO/HI: `stride` (generic) or 0.. see below
+  __device__ __forceinline__ double a(int c) const { return A[c * stride]; }
+  __device__ __forceinline__ double b(int c) const { return B[c * stride]; }
+  __device__ __forceinline__ double lo(int c) const { return LO[c * lim_stride]; }
+  __device__ __forceinline__ double hi(int c) const { return HI[c * lim_stride]; }
+};
+
+// Rows of a joint-space sample computed on the fly from q' and q'' in global
+// memory (timeable_path_joint_spline.cc:320-343): rows 0..D-1 are the
+// acceleration rows (A = q', B = q''), rows D..2D-1 the velocity rows
+// (A = 0, B = q'^2). lim_lo / lim_hi are the per-path limits [2D].
+struct JointRowsAt {
+  const double *q12;  // &q1q2[sample][0]: q'[0..D) then q''[0..D)
+  const double *lim_lo, *lim_hi;
+  int D;
+  __device__ __forceinline__ double a(int c) const { return c < D ? q12[c] : 0.0; }
+  __device__ __forceinline__ double b(int c) const {
+    if (c < D) return q12[D + c];
+    const double v = q12[c - D];
+    return v * v;
+  }
+  __device__ __forceinline__ double lo(int c) const { return lim_lo[c]; }
+  __device__ __forceinline__ double hi(int c) const { return lim_hi[c]; }
+};
+
+// Rows of a sample stored explicitly in global memory ([C] each).
+struct GlobalRowsAt {
+  const double *A, *B, *LO, *HI;
+  __device__ __forceinline__ double a(int c) const { return A[c]; }
+  __device__ __forceinline__ double b(int c) const { return B[c]; }
+  __device__ __forceinline__ double lo(int c) const { return LO[c]; }
+  __device__ __forceinline__ double hi(int c) const { return HI[c]; }
+};
+
+// AreDerivativesValid, time_optimal_path_timing.cc:624-636 (one thread, all rows)
+template <class R>
+__device__ __forceinline__ bool rows_valid(const R &r, int C, double sdd, double sd2) {
+  for (int i = 0; i < C; i++) {
+    const double v = r.a(i) * sdd + r.b(i) * sd2;
+    if (v + kTiny < r.lo(i) || v - kTiny > r.hi(i)) return false;
+  }
+  return true;
+}
+
+// FindSddMax and FindSddMin in one pass (time_optimal_path_timing.cc:638-695).
+// The reference keeps "the largest (smallest) candidate that is valid"; the
+// order candidates are visited in does not change that value.
+template <class R>
+__device__ void find_sdd_both(const R &r, int C, double sd2, double *sdd_max, double *sdd_min) {
+  double smax = -DBL_MAX, smin = DBL_MAX;
+  for (int i = 0; i < C; i++) {
+    const double A = r.a(i);
+    if (!is_tiny(A)) {
+      const double bs = r.b(i) * sd2;
+      for (int w = 0; w < 2; w++) {
+        const double lim = w ? r.hi(i) : r.lo(i);
+        const double sddi = (lim - bs) / A;
+        if (((sddi > smax) || (sddi < smin)) && rows_valid(r, C, sddi, sd2)) {
+          if (sddi > smax) smax = sddi;
+          if (sddi < smin) smin = sddi;
+        }
+      }
+    }
+  }
+  if (smax == -DBL_MAX) smax = 0;
+  if (smin == DBL_MAX) smin = 0;
+  *sdd_max = smax;
+  *sdd_min = smin;
+}
+
+// ---------------------------------------------------------------------------
+// 2-variable LP: FindMaxSd2Simplex, time_optimal_path_timing.cc:1149-1363, with
+// IsOptimal :1105-1147. The reference's constraint_set_ / active_set_ vectors
+// become bit sets over the 2C (row, bound) slots in the reference's iteration
+// order: slot 2c = (c, upper), slot 2c+1 = (c, lower). Erase keeps order, ties
+// resolve by first-seen, exactly as the vectors do.
+// ---------------------------------------------------------------------------
+template <int WORDS>
+struct SlotSet {
+  uint64_t w[WORDS];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) w[i] = 0;
+  }
+  __device__ __forceinline__ void fill(int n) {
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) {
+      const int lo = i * 64;
+      w[i] = (n >= lo + 64) ? ~0ull : (n > lo ? ((1ull << (n - lo)) - 1ull) : 0ull);
+    }
+  }
+  __device__ __forceinline__ void set(int s) {
+#pragma unroll
+    for (int i = 0; i < WORDS; i++)
+      if ((s >> 6) == i) w[i] |= 1ull << (s & 63);
+  }
+  __device__ __forceinline__ bool any() const {
+    uint64_t o = 0;
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) o |= w[i];
+    return o != 0;
+  }
+  __device__ __forceinline__ int count() const {
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) n += __popcll(w[i]);
+    return n;
+  }
+  __device__ __forceinline__ void remove(const SlotSet &o) {
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) w[i] &= ~o.w[i];
+  }
+  // smallest slot >= from, or -1
+  __device__ __forceinline__ int next(int from) const {
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) {
+      const int base = i * 64;
+      if (from < base + 64) {
+        uint64_t m = w[i];
+        if (from > base) m &= ~0ull << (from - base);
+        if (m) return base + __ffsll((long long)m) - 1;
+      }
+    }
+    return -1;
+  }
+};
+
+template <class R>
+__device__ __forceinline__ bool lp_pair_optimal(const R &r, int s1, int s2) {
+  const int first = s1 >> 1, second = s2 >> 1;
+  const bool first_upper = !(s1 & 1), second_upper = !(s2 & 1);
+  const double a1 = r.a(first), a2 = r.a(second);
+  const double denom = a2 * r.b(first) - a1 * r.b(second);
+  if (fabs(denom) < kTiny) return false;
+  const double t1 = denom * a1;
+  const double t2 = denom * (-a2);
+  if (first_upper) {
+    if (second_upper) return t1 <= 0 && t2 <= 0;
+    return t1 >= 0 && t2 <= 0;
+  }
+  if (second_upper) return t1 <= 0 && t2 >= 0;
+  return t1 >= 0 && t2 >= 0;
+}
+
+template <int WORDS, class R>
+__device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddmax,
+                                double *sd2zero) {
+  typedef SlotSet<WORDS> Set;
+  Set cset, act;
+  cset.fill(2 * C);
+  act.clear();
+
+  // Step 2: largest feasible sd2 on the line sdd = 0.
+  double sd2 = DBL_MAX, sdd = 0.0;
+  for (int c = 0; c < C; c++) {
+    const double Bc = r.b(c);
+    if (fabs(Bc) < kTiny) continue;
+    if (Bc > kTiny) {
+      const double invB = 1.0 / Bc;
+      const double tmp = r.hi(c) * invB;
+      if (tmp < (sd2 + kTiny) && tmp > 0) {
+        if (tmp < sd2 - kTiny) act.clear();
+        act.set(2 * c);
+        sd2 = tmp;
+      }
+    } else if (Bc < -kTiny) {
+      const double invB = 1.0 / Bc;
+      const double tmp = r.lo(c) * invB;
+      if (tmp < (sd2 + kTiny) && tmp > 0) {
+        if (tmp < sd2 - kTiny) act.clear();
+        act.set(2 * c + 1);
+        sd2 = tmp;
+      }
+    }
+  }
+  if (sd2 > kMaxSd2 || !act.any()) {
+    *sd2zero = kMaxSd2;
+    *sd2max = kMaxSd2;
+    *sddmax = 0.0;
+    return;
+  }
+  *sd2zero = sd2;
+
+  // Step 3 at the start point. slope = |A * (1/B)| as pushed at .cc:1199-1212.
+  int search = act.next(0);
+  if (act.count() >= 2) {
+    double best_slope = fabs(r.a(search >> 1) * (1.0 / r.b(search >> 1)));
+    for (int s1 = act.next(0); s1 >= 0; s1 = act.next(s1 + 1)) {
+      const double slope = fabs(r.a(s1 >> 1) * (1.0 / r.b(s1 >> 1)));
+      if (slope < best_slope) {
+        best_slope = slope;
+        search = s1;
+      }
+      for (int s2 = act.next(s1 + 1); s2 >= 0; s2 = act.next(s2 + 1)) {
+        if (lp_pair_optimal(r, s1, s2)) {
+          *sd2max = sd2;
+          *sddmax = 0.0;
+          return;
+        }
+      }
+    }
+  }
+  cset.remove(act);
+
+  for (int loop = 0; loop < C; loop++) {
+    // The reference would index row -1 here if every slope was not < max()
+    // (.cc:1322-1331 then :1260); treat as its "no optimum" fallback.
+    if (search < 0) break;
+    const int sc = search >> 1;
+    const double As = r.a(sc);
+    if (fabs(As) < kTiny) {
+      *sd2max = sd2;
+      *sddmax = sdd;
+      return;
+    }
+    // search line sdd = a + b * sd2
+    const double invA = 1.0 / As;
+    const double b = -r.b(sc) * invA;
+    const double a = (search & 1) ? r.lo(sc) * invA : r.hi(sc) * invA;
+
+    act.clear();
+    double next_sd2 = DBL_MAX, next_sdd = 0.0;
+    for (int s = cset.next(0); s >= 0; s = cset.next(s + 1)) {
+      const int c = s >> 1;
+      const double Ac = r.a(c);
+      const double Bc = Ac * b + r.b(c);
+      if (fabs(Bc) < kTiny) continue;
+      const double invB = 1.0 / Bc;
+      const double lim = (s & 1) ? r.lo(c) : r.hi(c);
+      const double tmp = (lim - Ac * a) * invB;
+      if (tmp < (next_sd2 + kTiny) && tmp > sd2) {
+        if (tmp < next_sd2 - kTiny) act.clear();
+        act.set(s);
+        next_sd2 = tmp;
+        next_sdd = a + b * next_sd2;
+      }
+    }
+    if (!act.any()) {
+      *sd2max = *sd2zero;
+      *sddmax = 0.0;
+      return;
+    }
+    // Step 3: optimality of {active set, previous search} and next direction.
+    const int old_search = search;
+    search = -1;
+    double best_slope = DBL_MAX;
+    for (int s1 = act.next(0); s1 >= 0; s1 = act.next(s1 + 1)) {
+      const int c1 = s1 >> 1;
+      const double Ac = r.a(c1);
+      const double slope = fabs(Ac * (1.0 / (Ac * b + r.b(c1))));
+      if (slope < best_slope) {
+        best_slope = slope;
+        search = s1;
+      }
+      bool opt = false;
+      for (int s2 = act.next(s1 + 1); s2 >= 0 && !opt; s2 = act.next(s2 + 1))
+        opt = lp_pair_optimal(r, s1, s2);
+      if (!opt) opt = lp_pair_optimal(r, s1, old_search);  // previous search is last
+      if (opt) {
+        *sd2max = next_sd2;
+        *sddmax = next_sdd;
+        if (next_sd2 > kMaxSd2) {
+          *sd2max = kMaxSd2;
+          *sddmax = 0.0;
+        }
+        return;
+      }
+    }
+    cset.remove(act);
+    sd2 = next_sd2;
+    sdd = next_sdd;
+  }
+  *sd2max = *sd2zero;
+  *sddmax = 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// Degree-2 B-spline: knot span (splines/bspline_base.cc:218-246), basis and
+// derivatives up to order 2 (NURBS A2.3 as restated at :268-348, unrolled for
+// p = 2, der = 2; every product, quotient and sum keeps the generic
+// algorithm's order, including the additions of zero-valued "saved").
+// ders[k][j], k = derivative order, j = basis index.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int knot_span_deg2(const double *knots, int num_knots, double u) {
+  if (u == knots[num_knots - 1]) return num_knots - 2 - 2;
+  int lo = 2, hi = num_knots - 2;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (knots[mid] <= u) lo = mid + 1; else hi = mid;
+  }
+  return lo - 1;
+}
+
+__device__ __forceinline__ void basis_ders_deg2(const double *knots, int span, double u,
+                                                double ders[3][3]) {
+  double ndu[3][3];
+  const double left1 = u - knots[span];
+  const double right1 = knots[span + 1] - u;
+  const double left2 = u - knots[span - 1];
+  const double right2 = knots[span + 2] - u;
+  ndu[0][0] = 1.0;
+  // j = 1
+  {
+    double saved = 0.0;
+    ndu[1][0] = right1 + left1;
+    const double tmp = ndu[0][0] / ndu[1][0];
+    ndu[0][1] = saved + right1 * tmp;
+    saved = left1 * tmp;
+    ndu[1][1] = saved;
+  }
+  // j = 2
+  {
+    double saved = 0.0;
+    ndu[2][0] = right1 + left2;
+    double tmp = ndu[0][1] / ndu[2][0];
+    ndu[0][2] = saved + right1 * tmp;
+    saved = left2 * tmp;
+    ndu[2][1] = right2 + left1;
+    tmp = ndu[1][1] / ndu[2][1];
+    ndu[1][2] = saved + right2 * tmp;
+    saved = left1 * tmp;
+    ndu[2][2] = saved;
+  }
+  ders[0][0] = ndu[0][2];
+  ders[0][1] = ndu[1][2];
+  ders[0][2] = ndu[2][2];
+
+  // r = 0: k=1: rk=-1,pk=1: j1=1,j2=0 (empty); r<=pk: a[1][1] = -a[0][0]/ndu[2][0]
+  //        k=2: rk=-2,pk=0: j1=2,j2=1 (empty); r<=pk: a[0][2] = -a[1][1]/ndu[1][0]
+  {
+    const double a00 = 1.0;
+    double d = 0.0;
+    const double a11 = -a00 / ndu[2][0];
+    d += a11 * ndu[0][1];
+    ders[1][0] = d;
+    d = 0.0;
+    const double a02 = -a11 / ndu[1][0];
+    d += a02 * ndu[0][0];
+    ders[2][0] = d;
+  }
+  // r = 1: k=1: rk=0,pk=1: r>=k: a[1][0] = a[0][0]/ndu[2][0], d = a10*ndu[0][1];
+  //             j1=1, j2=0 (r-1<=pk -> k-1=0): empty; r<=pk: a[1][1] = -a[0][0]/ndu[2][1]
+  //        k=2: rk=-1,pk=0: r<k; j1=1; r-1<=pk -> j2=1:
+  //             a[0][1] = (a[1][1]-a[1][0])/ndu[1][0]; d += a01*ndu[0][0]; r<=pk? 1<=0 no.
+  {
+    const double a00 = 1.0;
+    double d = 0.0;
+    const double a10 = a00 / ndu[2][0];
+    d = a10 * ndu[0][1];
+    const double a11 = -a00 / ndu[2][1];
+    d += a11 * ndu[1][1];
+    ders[1][1] = d;
+    d = 0.0;
+    const double a01 = (a11 - a10) / ndu[1][0];
+    d += a01 * ndu[0][0];
+    ders[2][1] = d;
+  }
+  // r = 2: k=1: rk=1,pk=1: a[1][0] = a[0][0]/ndu[2][1], d = a10*ndu[1][1];
+  //             j1=1; r-1<=pk (1<=1) -> j2=0: empty; r<=pk? no.
+  //        k=2: rk=0,pk=0: a[0][0]' = a[1][0]/ndu[1][0], d = that*ndu[0][0];
+  //             j1=1; r-1<=pk? 1<=0 no -> j2=p-r=0: empty; r<=pk? no.
+  {
+    const double a00 = 1.0;
+    double d;
+    const double a10 = a00 / ndu[2][1];
+    d = a10 * ndu[1][1];
+    ders[1][2] = d;
+    const double a00b = a10 / ndu[1][0];
+    d = a00b * ndu[0][0];
+    ders[2][2] = d;
+  }
+  // factors: row 1 *= p (=2); row 2 *= p*(p-1) (=2)
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    ders[1][j] *= 2.0;
+    ders[2][j] *= 2.0;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Wave-level helpers (64 lanes).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = (o > v) ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(v, off, 64);
+    v = (o < v) ? o : v;
+  }
+  return v;
+}
+__device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
+  return __shfl(v, src_lane, 64);
+}
+
+}  // namespace tpamd

@@ -1,0 +1,918 @@
+// tpamd_kernels.h -- HIP kernels of the batched path-timing engine (gfx950).
+//
+// Pipeline for one batch (all on one stream):
+//   k_setup_*          one thread per path: ds, limits, setup validation
+//   k_sample_lp_joint  one thread per (path, sample): degree-2 B-spline q,q',q'',
+//   / k_lp_rows        constraint rows, LP boundary point, FindSddMax/Min
+//   k_boundary_detect  one thread per (path, sample): isolated points and skipped
+//                      maxima of the boundary curve (CalculateBoundary pass 2)
+//   k_boundary_final   one thread per (path, sample): deferred fixes (pass 3) and
+//                      sink/source/trajectory classification (pass 4)
+//   k_sweep            one 64-lane wave per path: backward/forward extremals,
+//                      switching-point loop, sqrt, time integration
+//   k_epilogue         one thread per (path, sample): qd, qdd
+#pragma once
+
+#include "tpamd_device.h"
+
+namespace tpamd {
+
+// ------------------------------------------------------------------ workspace
+struct Workspace {
+  // per path
+  double *ds, *s_start, *s_end, *sd_start, *sdd_start, *t_start, *delta;
+  uint32_t *err_bits;
+  double *lim;  // [B][2][C] lower then upper (joint mode)
+  // per (path, sample)
+  double *q12;  // [B][N][2D] (joint mode)
+  double *m0, *z0, *X0, *Y0, *Xz, *Yz;  // pass-1 boundary, [B][N]
+  uint8_t *at0;                          // sd2_max_at_sdd0
+  uint8_t *fix_flag;
+  double *fix_val;
+  double *m, *X, *Y;  // final boundary
+  uint8_t *type;
+  double *sd2;
+};
+
+struct JointSource {
+  const double *q12;  // [B][N][2D]
+  const double *lim;  // [B][2][2D]
+  int D;
+  __device__ __forceinline__ int rows() const { return 2 * D; }
+  __device__ __forceinline__ JointRowsAt at(int b, int N, int idx) const {
+    JointRowsAt r;
+    r.q12 = q12 + ((size_t)b * N + idx) * (2 * D);
+    r.lim_lo = lim + (size_t)b * 4 * D;
+    r.lim_hi = r.lim_lo + 2 * D;
+    r.D = D;
+    return r;
+  }
+};
+
+struct GenericSource {
+  const double *A, *B, *LO, *HI;  // [B][N][C]
+  int C;
+  __device__ __forceinline__ int rows() const { return C; }
+  __device__ __forceinline__ GlobalRowsAt at(int b, int N, int idx) const {
+    const size_t o = ((size_t)b * N + idx) * C;
+    GlobalRowsAt r;
+    r.A = A + o; r.B = B + o; r.LO = LO + o; r.HI = HI + o;
+    return r;
+  }
+};
+
+// --------------------------------------------------------------------- setup
+// Joint mode: InitSolver/SetupProblem checks that do not need per-sample data
+// (time_optimal_path_timing.cc:165-193, :554-576) plus the limit rows of
+// timeable_path_joint_spline.cc:327-339. s_end = path_start + delta*(N-1) as
+// path_timing_trajectory.cc:340-341.
+__global__ void k_setup_joint(int B, int N, int D, double safety, const double *vmax,
+                              const double *amax, const double *path_start,
+                              const double *delta, const double *sd_start,
+                              const double *sdd_start, const double *t_start, Workspace ws) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int C = 2 * D;
+  double *lo = ws.lim + (size_t)b * 2 * C, *hi = lo + C;
+  double maxw = -DBL_MAX;
+  bool lower_ge_upper = false;
+  for (int d = 0; d < D; d++) {
+    const double a = amax[(size_t)b * D + d] * safety;
+    const double na = -amax[(size_t)b * D + d] * safety;
+    const double v = vmax[(size_t)b * D + d] * safety;
+    hi[d] = a;
+    lo[d] = na;
+    hi[D + d] = v * v;
+    lo[D + d] = 0.0;
+  }
+  for (int c = 0; c < C; c++) {
+    const double w = hi[c] - lo[c];
+    if (w > maxw) maxw = w;
+    if (lo[c] >= hi[c]) lower_ge_upper = true;
+  }
+  const double s0 = path_start[b];
+  const double s1 = s0 + delta[b] * (N - 1);
+  uint32_t bits = 0;
+  if (maxw <= 0) bits |= kErrInfeasible;
+  if (s0 >= s1) bits |= kErrSRange;
+  if (sd_start[b] < 0) bits |= kErrSdStartNeg;
+  if (lower_ge_upper) bits |= kErrLowerGeUpper;
+  if (N < 2) bits |= kErrTooFew;
+  ws.err_bits[b] = bits;
+  ws.s_start[b] = s0;
+  ws.s_end[b] = s1;
+  ws.ds[b] = (s1 - s0) / (N - 1);
+  ws.sd_start[b] = sd_start[b];
+  ws.sdd_start[b] = sdd_start ? sdd_start[b] : 0.0;
+  ws.t_start[b] = t_start[b];
+  ws.delta[b] = delta[b];
+}
+
+__global__ void k_setup_rows(int B, int N, const double *s_start, const double *s_end,
+                             const double *sd_start, const double *sdd_start,
+                             const double *t_start, Workspace ws) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  uint32_t bits = 0;
+  if (s_start[b] >= s_end[b]) bits |= kErrSRange;
+  if (sd_start[b] < 0) bits |= kErrSdStartNeg;
+  if (N < 2) bits |= kErrTooFew;
+  ws.err_bits[b] = bits;  // per-sample bits are OR-ed in by k_lp_rows
+  ws.s_start[b] = s_start[b];
+  ws.s_end[b] = s_end[b];
+  ws.ds[b] = (s_end[b] - s_start[b]) / (N - 1);
+  ws.sd_start[b] = sd_start[b];
+  ws.sdd_start[b] = sdd_start ? sdd_start[b] : 0.0;
+  ws.t_start[b] = t_start[b];
+}
+
+// ------------------------------------------------- pass 1, common tail per sample
+template <int WORDS, class R>
+__device__ __forceinline__ void boundary_point(const R &r, int C, size_t o, Workspace ws) {
+  double sd2max, sddmax, sd2zero;
+  lp_find_max_sd2<WORDS>(r, C, &sd2max, &sddmax, &sd2zero);
+  double x0, y0, xz, yz;
+  find_sdd_both(r, C, sd2max, &x0, &y0);
+  if (sd2zero == sd2max) {
+    xz = x0; yz = y0;
+  } else {
+    find_sdd_both(r, C, sd2zero, &xz, &yz);
+  }
+  ws.m0[o] = sd2max;
+  ws.z0[o] = sd2zero;
+  ws.X0[o] = x0;
+  ws.Y0[o] = y0;
+  ws.Xz[o] = xz;
+  ws.Yz[o] = yz;
+  ws.at0[o] = fabs(sd2max - sd2zero) < kTiny;
+}
+
+// ---------------------------------------------------- K1 (joint): sample + LP
+// grid = (ceil(N/TPB), B), block = TPB. Dynamic LDS:
+//   knots[P+3] | control points [P][D] | lim_lo[2D] | lim_hi[2D] | A[2D][TPB] | B[2D][TPB]
+// SamplePath: timeable_path_joint_spline.cc:294-318; EvalCurveAndDerivatives:
+// splines/bspline.h:540-568; ConstraintSetup: timeable_path_joint_spline.cc:320-343;
+// CalculateBoundary pass 1: time_optimal_path_timing.cc:1366-1377.
+template <int WORDS>
+__global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
+                                  const double *cps_g, double *q_out, Workspace ws) {
+  extern __shared__ double lds[];
+  const int TPB = blockDim.x;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int K = P + 3;
+  const int C = 2 * D;
+  double *s_knots = lds;
+  double *s_cp = s_knots + K;
+  double *s_lo = s_cp + P * D;
+  double *s_hi = s_lo + C;
+  double *s_A = s_hi + C;
+  double *s_B = s_A + (size_t)C * TPB;
+  for (int k = tid; k < K; k += TPB) s_knots[k] = knots_g[(size_t)b * K + k];
+  for (int k = tid; k < P * D; k += TPB) s_cp[k] = cps_g[(size_t)b * P * D + k];
+  for (int k = tid; k < 2 * C; k += TPB) s_lo[k] = ws.lim[(size_t)b * 2 * C + k];
+  __syncthreads();
+  const int i = blockIdx.x * TPB + tid;
+  if (i >= N) return;
+  const size_t o = (size_t)b * N + i;
+
+  const double path_start = ws.s_start[b];
+  const double delta = ws.delta[b];
+  const double k0 = s_knots[0], kend = s_knots[K - 1];
+  const double parameter = path_start + i * delta;
+  double *q12 = ws.q12 + o * C;
+  double *A = s_A + tid, *Bv = s_B + tid;
+  if (parameter < kend + delta) {
+    double u = parameter;
+    if (u < k0) u = k0;
+    if (kend < u) u = kend;
+    const int span = knot_span_deg2(s_knots, K, u);
+    double ders[3][3];
+    basis_ders_deg2(s_knots, span, u, ders);
+    const double *p0 = s_cp + (size_t)(span - 2) * D, *p1 = p0 + D, *p2 = p1 + D;
+    for (int d = 0; d < D; d++) {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      v0 += ders[0][0] * p0[d]; v0 += ders[0][1] * p1[d]; v0 += ders[0][2] * p2[d];
+      v1 += ders[1][0] * p0[d]; v1 += ders[1][1] * p1[d]; v1 += ders[1][2] * p2[d];
+      v2 += ders[2][0] * p0[d]; v2 += ders[2][1] * p1[d]; v2 += ders[2][2] * p2[d];
+      if (q_out) q_out[o * D + d] = v0;
+      q12[d] = v1;
+      q12[D + d] = v2;
+      A[d * TPB] = v1;
+      Bv[d * TPB] = v2;
+      A[(D + d) * TPB] = 0.0;
+      Bv[(D + d) * TPB] = v1 * v1;
+    }
+  } else {
+    const double *pl = s_cp + (size_t)(P - 1) * D;
+    for (int d = 0; d < D; d++) {
+      if (q_out) q_out[o * D + d] = pl[d];
+      q12[d] = 0.0;
+      q12[D + d] = 0.0;
+      A[d * TPB] = 0.0;
+      Bv[d * TPB] = 0.0;
+      A[(D + d) * TPB] = 0.0;
+      Bv[(D + d) * TPB] = 0.0;
+    }
+  }
+  LdsRows r;
+  r.A = A; r.B = Bv; r.LO = s_lo; r.HI = s_hi; r.stride = TPB; r.lim_stride = 1;
+  boundary_point<WORDS>(r, C, o, ws);
+}
+
+// ------------------------------------------------ K1 (rows): validation + LP
+// grid = (ceil(N/TPB), B). Dynamic LDS: A,B,LO,HI each [C][TPB].
+template <int WORDS>
+__global__ void k_lp_rows(int N, int C, const double *Ag, const double *Bg, const double *LOg,
+                          const double *HIg, Workspace ws) {
+  extern __shared__ double lds[];
+  const int TPB = blockDim.x;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  double *s_A = lds, *s_B = s_A + (size_t)C * TPB, *s_LO = s_B + (size_t)C * TPB,
+         *s_HI = s_LO + (size_t)C * TPB;
+  const int i0 = blockIdx.x * TPB;
+  const int nvalid = min(TPB, N - i0);
+  const size_t base = ((size_t)b * N + i0) * C;
+  for (int k = tid; k < nvalid * C; k += TPB) {
+    const int s = k / C, c = k - s * C;
+    s_A[c * TPB + s] = Ag[base + k];
+    s_B[c * TPB + s] = Bg[base + k];
+    s_LO[c * TPB + s] = LOg[base + k];
+    s_HI[c * TPB + s] = HIg[base + k];
+  }
+  __syncthreads();
+  if (tid >= nvalid) return;
+  const size_t o = (size_t)b * N + i0 + tid;
+  LdsRows r;
+  r.A = s_A + tid; r.B = s_B + tid; r.LO = s_LO + tid; r.HI = s_HI + tid;
+  r.stride = TPB; r.lim_stride = TPB;
+  double maxw = -DBL_MAX;
+  bool lge = false;
+  for (int c = 0; c < C; c++) {
+    const double w = r.hi(c) - r.lo(c);
+    if (w > maxw) maxw = w;
+    if (r.lo(c) >= r.hi(c)) lge = true;
+  }
+  uint32_t bits = 0;
+  if (maxw <= 0) bits |= kErrInfeasible;
+  if (lge) bits |= kErrLowerGeUpper;
+  if (bits) atomicOr(&ws.err_bits[b], bits);
+  boundary_point<WORDS>(r, C, o, ws);
+}
+
+// Stand-alone batched LP (tpamd_find_max_sd2_host): one thread per LP.
+template <int WORDS>
+__global__ void k_lp_only(int num, int C, const double *Ag, const double *Bg,
+                          const double *LOg, const double *HIg, double *sd2max,
+                          double *sddmax, double *sd2zero) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= num) return;
+  GlobalRowsAt r;
+  r.A = Ag + (size_t)i * C; r.B = Bg + (size_t)i * C;
+  r.LO = LOg + (size_t)i * C; r.HI = HIg + (size_t)i * C;
+  lp_find_max_sd2<WORDS>(r, C, &sd2max[i], &sddmax[i], &sd2zero[i]);
+}
+
+// ------------------------------------------- K1b: CalculateBoundary pass 2
+// time_optimal_path_timing.cc:1381-1431. The reference walks i = 1..N-2 and
+// (a) rewrites the neighbours of isolated points in place, (b) tests sample i
+// against the state left by iterations <= i. Both are functions of pass-1 data
+// only, so every i is evaluated independently here:
+//   iso(i)   = !at[i-1] && at[i] && !at[i+1]
+//   element j as seen by iteration k: rewritten as "left of iso(j+1)" if
+//   j+1 <= k, else as "right of iso(j-1)" if j-1 <= k, else untouched.
+//   A rewritten element has sd2_max = sd2_max_for_sdd0 and sdd_max = FindSddMax
+//   there; its sdd_min is FindSddMin there for a left rewrite and FindSddMax
+//   there for a right rewrite (the reference's line :1394-1395).
+__device__ __forceinline__ bool iso_at(const uint8_t *at, int N, int i) {
+  return (i >= 1) && (i <= N - 2) && !at[i - 1] && at[i] && !at[i + 1];
+}
+
+__global__ void k_boundary_detect(int N, Workspace ws) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const size_t pb = (size_t)b * N;
+  if (k < 1 || k > N - 2) {
+    ws.fix_flag[pb + k] = 0;
+    return;
+  }
+  const uint8_t *at = ws.at0 + pb;
+  const double *m0 = ws.m0 + pb, *z0 = ws.z0 + pb, *X0 = ws.X0 + pb, *Y0 = ws.Y0 + pb,
+               *Xz = ws.Xz + pb, *Yz = ws.Yz + pb;
+  const double ds = ws.ds[b];
+  const bool iso_k = iso_at(at, N, k), iso_km1 = iso_at(at, N, k - 1),
+             iso_km2 = iso_at(at, N, k - 2);
+  // element k-1
+  const bool l_mod = iso_k || iso_km2;
+  const double m_l = l_mod ? z0[k - 1] : m0[k - 1];
+  const double fsmax_l = l_mod ? Xz[k - 1] : X0[k - 1];  // FindSddMax(k-1, m_l)
+  // element k
+  const double m_c = iso_km1 ? z0[k] : m0[k];
+  const double X_c = iso_km1 ? Xz[k] : X0[k];
+  const double Y_c = iso_km1 ? Xz[k] : Y0[k];
+  // element k+1
+  const double m_r = iso_k ? z0[k + 1] : m0[k + 1];
+  const double Y_r = iso_k ? Xz[k + 1] : Y0[k + 1];
+  const double fsmin_r = iso_k ? Yz[k + 1] : Y0[k + 1];  // FindSddMin(k+1, m_r)
+
+  const double sd2p = (m_r - m_c) / ds;
+  const double sd2p_min = 2 * Y_c;
+  const double sd2p_max = 2 * X_c;
+  const bool sink_or_source = (sd2p < sd2p_min) || (sd2p > sd2p_max);
+  const bool skipped_sdd = (X_c > 0) && (Y_r < 0);
+  const bool skipped_sd2 = (m_c > m_l - kTiny) && (m_c > m_r - kTiny);
+  uint8_t flag = 0;
+  double val = 0.0;
+  if ((skipped_sd2 || skipped_sdd) && sink_or_source) {
+    const double fw = m_l + 2.0 * ds * fsmax_l;  // OneForwardExtremalStep(k-1, m_l), .cc:753-759
+    const double bw = m_r - 2.0 * ds * fsmin_r;  // OneBackwardExtremalStep(k+1, m_r), .cc:761-767
+    double mn = z0[k];
+    if (fw < mn) mn = fw;
+    if (bw < mn) mn = bw;
+    val = (0.0 < mn) ? mn : 0.0;
+    flag = 1;
+  }
+  ws.fix_flag[pb + k] = flag;
+  ws.fix_val[pb + k] = val;
+}
+
+// ---------------------------------- K1c: CalculateBoundary passes 3 and 4
+// time_optimal_path_timing.cc:1432-1484. The deferred list is applied in
+// ascending index order, each entry k writing k, then k-1, then k+1; the last
+// writer of element j is therefore entry j+1 (sdd0 values), else entry j (its
+// value), else entry j-1 (sdd0 values), else the pass-2 state.
+__device__ __forceinline__ double final_m(const Workspace &ws, size_t pb, int N, int j) {
+  const uint8_t *ff = ws.fix_flag + pb;
+  if (j + 1 <= N - 2 && ff[j + 1]) return ws.z0[pb + j];
+  if (ff[j]) return ws.fix_val[pb + j];
+  if (j >= 1 && ff[j - 1]) return ws.z0[pb + j];
+  const uint8_t *at = ws.at0 + pb;
+  if (iso_at(at, N, j + 1) || iso_at(at, N, j - 1)) return ws.z0[pb + j];
+  return ws.m0[pb + j];
+}
+
+template <class Source>
+__global__ void k_boundary_final(int N, Source src, Workspace ws) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const size_t pb = (size_t)b * N;
+  const uint8_t *ff = ws.fix_flag + pb;
+  const uint8_t *at = ws.at0 + pb;
+  double m, X, Y;
+  const bool f_next = (j + 1 <= N - 2) && ff[j + 1];
+  const bool f_self = ff[j];
+  const bool f_prev = (j >= 1) && ff[j - 1];
+  if (f_next || (!f_self && f_prev)) {
+    m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
+  } else if (f_self) {
+    m = ws.fix_val[pb + j];
+    const auto r = src.at(b, N, j);
+    find_sdd_both(r, src.rows(), m, &X, &Y);
+  } else if (iso_at(at, N, j + 1)) {
+    m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
+  } else if (iso_at(at, N, j - 1)) {
+    m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Xz[pb + j];  // sic, .cc:1394-1395
+  } else {
+    m = ws.m0[pb + j]; X = ws.X0[pb + j]; Y = ws.Y0[pb + j];
+  }
+  ws.m[pb + j] = m;
+  ws.X[pb + j] = X;
+  ws.Y[pb + j] = Y;
+  uint8_t type = kBndNone;
+  if (j >= 1 && j <= N - 2) {
+    const double m_next = final_m(ws, pb, N, j + 1);
+    const double ds = ws.ds[b];
+    const double sd2p = (m_next - m) / ds;
+    const double sd2p_min = 2 * Y;
+    const double sd2p_max = 2 * X;
+    if (sd2p < sd2p_min) type = kBndSink;
+    else if (sd2p > sd2p_max) type = kBndSource;
+    if ((sd2p <= sd2p_max) && (sd2p >= sd2p_min)) type = kBndTrajectory;
+  }
+  ws.type[pb + j] = type;
+}
+
+// ------------------------------------------------------------- K2: the sweep
+// One 64-lane wave per path. All solver scalars are wave-uniform (every lane
+// computes the same values); lanes split the candidate/row work of
+// FindSddMax/FindSddMin/AreDerivativesValid and the index ranges of the
+// search/fill/scan loops. sd2_ and sdd_ live in LDS.
+template <class Source>
+struct Sweep {
+  Source src;
+  int b, N, C, lane;
+  double ds;
+  double *sd2, *sdd;   // LDS [N]
+  const double *m;     // final sd2_max [N]
+  const uint8_t *type; // final classification [N]
+
+  __device__ __forceinline__ void put_sd2(int i, double v) {
+    if (lane == 0) sd2[i] = v;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void put_sdd(int i, double v) {
+    if (lane == 0) sdd[i] = v;
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // FindSddMax (want_max) / FindSddMin, time_optimal_path_timing.cc:638-695:
+  // candidates are spread over lanes, each lane validates its candidate against
+  // all rows, a wave reduction keeps the extreme valid candidate.
+  __device__ double find_sdd(int idx, double s2, bool want_max) const {
+    const auto r = src.at(b, N, idx);
+    double best = want_max ? -DBL_MAX : DBL_MAX;
+    for (int c = lane; c < 2 * C; c += 64) {
+      const int i = c >> 1;
+      const double A = r.a(i);
+      if (!is_tiny(A)) {
+        const double lim = (c & 1) ? r.hi(i) : r.lo(i);
+        const double sddi = (lim - r.b(i) * s2) / A;
+        const bool better = want_max ? (sddi > best) : (sddi < best);
+        if (better && rows_valid(r, C, sddi, s2)) best = sddi;
+      }
+    }
+    if (want_max) {
+      best = wave_max_f64(best);
+      if (best == -DBL_MAX) best = 0;
+    } else {
+      best = wave_min_f64(best);
+      if (best == DBL_MAX) best = 0;
+    }
+    return best;
+  }
+
+  // AreDerivativesValid (.cc:624-636) with rows spread over lanes.
+  __device__ bool derivs_valid(int idx, double sddv, double s2) const {
+    const auto r = src.at(b, N, idx);
+    bool bad = false;
+    for (int i = lane; i < C; i += 64) {
+      const double v = r.a(i) * sddv + r.b(i) * s2;
+      if (v + kTiny < r.lo(i) || v - kTiny > r.hi(i)) bad = true;
+    }
+    return !__any(bad);
+  }
+
+  // ComputeSddAtIntersection, .cc:722-751
+  __device__ void sdd_at_intersection(int index) {
+    double cand[3];
+    int n = 0;
+    if (index > 0 && index < N - 1) cand[n++] = 0.25 / ds * (sd2[index + 1] - sd2[index - 1]);
+    if (index < N - 1) cand[n++] = 0.5 / ds * (sd2[index + 1] - sd2[index]);
+    if (index > 0) cand[n++] = 0.5 / ds * (sd2[index] - sd2[index - 1]);
+    double res = 0.0;
+    const double s2 = sd2[index];
+    for (int k = 0; k < n; k++) {
+      if (derivs_valid(index, cand[k], s2)) { res = cand[k]; break; }
+    }
+    put_sdd(index, res);
+  }
+
+  // AddForwardExtremal, .cc:769-857
+  __device__ int add_forward(int idx_lo) {
+    const double two_ds = 2.0 * ds;
+    for (int idx = idx_lo; idx < N - 2; idx++) {
+      const double cur = sd2[idx];
+      const double m_i = m[idx], m_n = m[idx + 1];
+      const uint8_t t_i = type[idx], t_n = type[idx + 1];
+      const bool on_boundary = is_tiny(cur - m_i);
+      double sd2tmp, sddtmp;
+      if (on_boundary && (t_i & kBndTrajectory) && (t_n & kBndTrajectory)) {
+        sd2tmp = m_n;
+        sddtmp = 0.5 * (sd2tmp - cur) / ds;
+      } else {
+        sddtmp = find_sdd(idx, cur, true);
+        sd2tmp = cur + two_ds * sddtmp;
+      }
+      const double nxt = sd2[idx + 1];
+      if (!isnan(nxt) && (nxt < sd2tmp)) {
+        sdd_at_intersection(idx);
+        return N - 1;
+      }
+      if (sd2tmp > m_n) {
+        const double sdd_bound = 0.5 * (m_n - cur) / ds;
+        const bool deriv_invalid = !derivs_valid(idx, sdd_bound, m_i);
+        const bool type_invalid = t_n & kBndSink;
+        if (type_invalid || deriv_invalid) return idx;
+        sd2tmp = m_n;
+        sddtmp = sdd_bound;
+      }
+      if (sd2tmp < 0) {
+        sd2tmp = 0.0;
+        if (idx <= 1) sddtmp = 0.0; else sddtmp = -sd2[idx - 1] / ds;
+      }
+      put_sd2(idx + 1, sd2tmp);
+      put_sdd(idx, sddtmp);
+    }
+    return N - 1;
+  }
+
+  // AddBackwardExtremal, .cc:859-952
+  __device__ int add_backward(int idx_hi) {
+    const double two_ds = 2.0 * ds;
+    for (int idx = idx_hi; idx > 1; idx--) {
+      const double cur = sd2[idx];
+      const double m_i = m[idx], m_p = m[idx - 1];
+      const uint8_t t_i = type[idx], t_p = type[idx - 1];
+      const bool on_boundary = is_tiny(cur - m_i);
+      double sd2tmp, sddtmp;
+      if (on_boundary && (t_i & kBndTrajectory) && (t_p & kBndTrajectory)) {
+        sd2tmp = m_p;
+        sddtmp = 0.5 * (cur - sd2tmp) / ds;
+      } else {
+        sddtmp = find_sdd(idx, cur, false);
+        sd2tmp = cur - two_ds * sddtmp;
+      }
+      const double prv = sd2[idx - 1];
+      if (!isnan(prv) && (prv < sd2tmp)) {
+        sdd_at_intersection(idx);
+        return 0;
+      }
+      if (sd2tmp > m_p) {
+        const double sdd_bound = 0.5 * (cur - m_p) / ds;
+        const bool deriv_invalid = !derivs_valid(idx, sdd_bound, cur);
+        const bool type_invalid = t_p & kBndSource;
+        const bool is_connecting = (idx_hi != (N - 1));
+        if ((type_invalid || deriv_invalid) && !is_connecting) return idx;
+        sd2tmp = m_p;
+        sddtmp = sdd_bound;
+      }
+      if (sd2tmp < 0) {
+        sd2tmp = 0.0;
+        if (idx < N - 1) sddtmp = sd2[idx + 1] / ds; else sddtmp = 0.0;
+      }
+      put_sd2(idx - 1, sd2tmp);
+      put_sdd(idx, sddtmp);
+    }
+    return 0;
+  }
+
+  // NextCriticalPoint, .cc:697-720, as two wave-parallel scans:
+  //  1. first idx in (lo, hi] classified source or trajectory -> c0 (none: -1);
+  //  2. first idx >= c0 whose sd2 is already set -> e (none: -1); the answer is
+  //     the last idx in (c0, e] with sd2_max[idx] == sd2_max_for_sdd0[0]
+  //     (sic, index 0, .cc:710), else c0.
+  __device__ int next_critical_point(int idx_lo, int idx_hi, double z00) const {
+    int c0 = -1;
+    for (int base = idx_lo + 1; base <= idx_hi && c0 < 0; base += 64) {
+      const int idx = base + lane;
+      const bool hit = (idx <= idx_hi) && (type[idx] & (kBndSource | kBndTrajectory));
+      const unsigned long long mask = __ballot(hit);
+      if (mask) c0 = base + __ffsll((long long)mask) - 1;
+    }
+    if (c0 < 0) return -1;
+    int crit = c0;
+    for (int base = c0; base <= idx_hi; base += 64) {
+      const int idx = base + lane;
+      const bool in = idx <= idx_hi;
+      const bool set = in && !isnan(sd2[idx]);
+      const bool isol = in && (idx > c0) && (m[idx] == z00);
+      const unsigned long long mset = __ballot(set);
+      unsigned long long miso = __ballot(isol);
+      if (mset) {
+        const int e = __ffsll((long long)mset) - 1;  // lane of the first set sample
+        if (e < 63) miso &= (2ull << e) - 1ull;
+        if (miso) crit = base + 63 - __clzll((long long)miso);
+        return crit;
+      }
+      if (miso) crit = base + 63 - __clzll((long long)miso);
+    }
+    return -1;
+  }
+};
+
+// Dynamic LDS: sd2[N] | sdd[N] | dt[64]
+template <class Source>
+__global__ void __launch_bounds__(64)
+k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s_out,
+        double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
+        int32_t *status_out) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const size_t pb = (size_t)b * N;
+  const uint32_t bits = ws.err_bits[b];
+  if (bits) {
+    if (lane == 0) {
+      status_out[b] = status_from_bits(bits);
+      if (lei_out) lei_out[b] = 0;
+      if (dtmax_out) dtmax_out[b] = -1.0;
+    }
+    return;
+  }
+  Sweep<Source> S;
+  S.src = src; S.b = b; S.N = N; S.C = src.rows(); S.lane = lane;
+  S.ds = ws.ds[b];
+  S.sd2 = lds; S.sdd = lds + N;
+  S.m = ws.m + pb; S.type = ws.type + pb;
+  double *sd2 = S.sd2, *sdd = S.sdd;
+  const double ds = S.ds;
+  const double sd_start = ws.sd_start[b];
+
+  for (int i = lane; i < N; i += 64) { sd2[i] = qnan(); sdd[i] = qnan(); }
+  __syncthreads();
+  if (lane == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
+  __syncthreads();
+
+  int status = 0;
+  int iforw_lo = 0, iback_hi = N - 1, iback_lo, iforw_hi, icrit, icrit_lo, icrit_hi;
+  iback_lo = S.add_backward(iback_hi);
+  iforw_hi = S.add_forward(iforw_lo);
+  icrit_hi = iback_lo;
+  if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
+    S.put_sd2(icrit_hi, qnan());
+    icrit_hi++;
+    iback_lo++;
+  }
+  icrit_lo = iforw_hi;
+  const double z00 = ws.z0[pb];
+  for (int loop = 0; loop < max_loops; loop++) {
+    if (iforw_hi >= icrit_hi) break;
+    icrit = S.next_critical_point(icrit_lo, icrit_hi, z00);
+    if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
+    if (icrit > 0 && icrit < N - 1) S.put_sd2(icrit, S.m[icrit]);
+    if (icrit < 1) { status = 10; break; }
+    if (S.m[icrit - 1] <= S.m[icrit]) {
+      iback_hi = icrit - 1;
+      S.put_sd2(icrit - 1, S.m[icrit - 1]);
+    } else {
+      iback_hi = icrit;
+    }
+    iback_lo = S.add_backward(iback_hi);
+    iforw_lo = icrit;
+    iforw_hi = S.add_forward(iforw_lo);
+    if (iback_lo > icrit_lo) { status = 7; break; }
+    icrit_lo = iforw_hi;
+  }
+  __syncthreads();
+
+  // NaN check and sdd fill-in (.cc:398-411); every index is independent.
+  if (status == 0) {
+    bool has_nan = false;
+    for (int base = 0; base < N; base += 64) {
+      const int idx = base + lane;
+      if (idx < N && isnan(sd2[idx])) has_nan = true;
+    }
+    if (__any(has_nan)) status = 8;
+  }
+  if (status == 0) {
+    const int C = S.C;
+    for (int base = 0; base < N; base += 64) {
+      const int idx = base + lane;
+      if (idx < N && isnan(sdd[idx])) {
+        const auto r = src.at(b, N, idx);
+        double cand[3];
+        int n = 0;
+        if (idx > 0 && idx < N - 1) cand[n++] = 0.25 / ds * (sd2[idx + 1] - sd2[idx - 1]);
+        if (idx < N - 1) cand[n++] = 0.5 / ds * (sd2[idx + 1] - sd2[idx]);
+        if (idx > 0) cand[n++] = 0.5 / ds * (sd2[idx] - sd2[idx - 1]);
+        double res = 0.0;
+        for (int k = 0; k < n; k++)
+          if (rows_valid(r, C, cand[k], sd2[idx])) { res = cand[k]; break; }
+        sdd[idx] = res;
+      }
+    }
+    __syncthreads();
+    // Enforce the start acceleration if admissible (.cc:413-416).
+    const double sdd_start = ws.sdd_start[b];
+    if (S.derivs_valid(0, sdd_start, sd2[0])) S.put_sdd(0, sdd_start);
+    if (sd2[N - 1] != 0) status = 9;
+  }
+  if (status != 0) {
+    if (lane == 0) {
+      status_out[b] = status;
+      if (lei_out) lei_out[b] = 0;
+      if (dtmax_out) dtmax_out[b] = -1.0;
+    }
+    return;
+  }
+
+  // last_extremal_index_ (.cc:430-445): scan down from N-2 for sdd > 0 or a
+  // sample on the boundary curve.
+  int lei = 0;
+  {
+    const int start = (1 > N - 2) ? 1 : N - 2;
+    bool found = false;
+    for (int top = start; top >= 1 && !found; top -= 64) {
+      const int idx = top - lane;
+      const bool hit = (idx >= 1) && (sdd[idx] > 0.0 || fabs(sd2[idx] - S.m[idx]) < kTiny);
+      const unsigned long long mask = __ballot(hit);
+      if (mask) { lei = top - (__ffsll((long long)mask) - 1); found = true; }
+    }
+  }
+
+  // sd = sqrt(sd2) (.cc:420), time integration (.cc:447-467). dt of 64 samples is
+  // computed in parallel; the running sum keeps the reference's left-to-right
+  // order (each lane re-adds the tile's increments in sequence).
+  double *dtl = lds + 2 * (size_t)N;
+  const double t0 = ws.t_start[b];
+  const double s0 = ws.s_start[b], s1 = ws.s_end[b];
+  double tprev = t0;  // time_[base-1]
+  double dtmax = 0.0;
+  for (int base = 0; base < N; base += 64) {
+    const int idx = base + lane;
+    double dt = 0.0;
+    bool zero_pair = false;
+    double sdv = 0.0;
+    if (idx < N) {
+      const double s2 = sd2[idx];
+      sdv = sqrt(s2);
+      if (idx >= 1) {
+        const double s2p = sd2[idx - 1];
+        if ((s2p > 0) || (s2 > 0)) {
+          dt = 2.0 * ds / (sqrt(s2p) + sdv);
+        } else {
+          zero_pair = true;
+        }
+      }
+    }
+    dtl[lane] = dt;
+    __syncthreads();
+    double t = tprev;
+    for (int k = 0; k < 64; k++) {
+      const double inc = dtl[k];
+      if (k <= lane) t += inc;
+    }
+    const double tlast = wave_bcast_f64(t, 63);
+    __syncthreads();
+    if (idx < N) {
+      t_out[pb + idx] = (idx == 0) ? t0 : t;
+      sd_out[pb + idx] = sdv;
+      s_out[pb + idx] = (idx == N - 1) ? s1 : ds * idx + s0;
+      ws.sd2[pb + idx] = sd2[idx];
+      if (dt > dtmax) dtmax = dt;
+    }
+    // zero acceleration across stationary pairs (.cc:463-465)
+    if (zero_pair) { sdd[idx - 1] = 0; }
+    __syncthreads();
+    if (zero_pair) { sdd[idx] = 0; }
+    __syncthreads();
+    tprev = tlast;
+  }
+  dtmax = wave_max_f64(dtmax);
+  __syncthreads();
+  for (int idx = lane; idx < N; idx += 64) sdd_out[pb + idx] = sdd[idx];
+  if (lane == 0) {
+    status_out[b] = 0;
+    if (lei_out) lei_out[b] = lei;
+    if (dtmax_out) dtmax_out[b] = dtmax;
+  }
+}
+
+// -------------------------------------------------------------- K3: epilogue
+// path_timing_trajectory.cc:458-472. One thread per (path, sample).
+__global__ void k_epilogue(int B, int N, int D, const double *q12, const double *sd,
+                           const double *sdd, const double *amax, const int32_t *status,
+                           double *qd, double *qdd) {
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (size_t)B * N) return;
+  const int b = (int)(o / N);
+  if (status[b] != 0) return;
+  const double v = sd[o], a = sdd[o];
+  const double v2 = v * v;
+  const double *p = q12 + o * 2 * D;
+  for (int d = 0; d < D; d++) {
+    const double q1 = p[d], q2 = p[D + d];
+    const double am = amax[(size_t)b * D + d];
+    if (qd) qd[o * D + d] = q1 * v;
+    if (qdd) {
+      double acc = q1 * a + q2 * v2;
+      if (acc < -am) acc = -am;
+      if (acc > am) acc = am;
+      qdd[o * D + d] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ s(t) query
+// GetPathParameterAndDerivatives, time_optimal_path_timing.cc:1549-1627, with
+// SampleIndexFromTime :1497-1524 (the bracket time[k] <= t < time[k+1] is unique
+// for a non-decreasing time array, so a plain binary search finds the same k).
+__global__ void k_query(int B, int N, int K, const double *time, const double *s,
+                        const double *sd, const int32_t *status, Workspace ws,
+                        const double *tq, double *os, double *osd, double *osdd,
+                        int32_t *ok) {
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (size_t)B * K) return;
+  const int b = (int)(o / K);
+  if (status && status[b] != 0) {
+    if (ok) ok[o] = 0;
+    return;
+  }
+  const double *tm = time + (size_t)b * N, *sp = s + (size_t)b * N, *sdp = sd + (size_t)b * N,
+               *sd2 = ws.sd2 + (size_t)b * N;
+  const double ds_ = ws.ds[b];
+  const double inv_ds = 1.0 / ds_;
+  const double t = tq[o];
+  int good = 1;
+  double rs, rsd, rsdd;
+  if (t <= tm[0]) {
+    rs = ws.s_start[b]; rsd = sdp[0]; rsdd = 0.5 * inv_ds * (sd2[1] - sd2[0]);
+  } else if (t >= tm[N - 1]) {
+    rs = ws.s_end[b]; rsd = sdp[N - 1]; rsdd = 0.0;
+  } else {
+    int lo = 0, hi = N - 1;  // invariant: tm[lo] <= t < tm[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (tm[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int k = lo;
+    const double dt = t - tm[k];
+    const double sda = sdp[k], sdb = sdp[k + 1];
+    const double sd2a = sd2[k], sd2b = sd2[k + 1];
+    if (sda > 0 || sdb > 0) {
+      double dsv = sda * dt + dt * dt * 0.25 * inv_ds * (sd2b - sd2a);
+      if (dsv > ds_) dsv = ds_;
+      if (dt < 0 || dsv < 0) good = 0;
+      const double cand = sp[k] + dsv;
+      rs = (sp[k + 1] < cand) ? sp[k + 1] : cand;
+      rsd = sqrt(sd2a + dsv * inv_ds * (sd2b - sd2a));
+      rsdd = 0.5 * inv_ds * (sd2b - sd2a);
+    } else {
+      rs = sp[k] + (sp[k + 1] - sp[k]) * dt / (tm[k + 1] - tm[k]);
+      rsd = 0.0; rsdd = 0.0;
+    }
+  }
+  os[o] = rs; osd[o] = rsd; osdd[o] = rsdd;
+  if (ok) ok[o] = good;
+}
+
+// ------------------------------------------------------- uniform-time resample
+// ResampleEquidistantlyInTime (path_timing_trajectory.cc:755-783) with
+// InterpolateAtTime (:709-753). The reference advances lower_index monotonically
+// (TimeAtPathSamplesLowerIndex :686-695: first index >= previous with
+// time[index+1] > t, else N-1); because the query times increase, that equals the
+// first index overall with time[index+1] > t, found here by binary search.
+// eigenmath::InterpolateLinear is restated as a + t*(b-a) (not in the reference
+// tree; ulp-level parity of the resampled values is unpinned).
+struct ResampleParams {
+  int B, N, D, max_out;
+  const double *time, *s, *sd, *sdd, *q, *qd, *qdd, *amax, *start_sec;
+  double time_step;
+  const int32_t *status;
+  double *ot, *os, *osd, *osdd, *oq, *oqd, *oqdd;
+  int32_t *count;
+};
+
+__device__ __forceinline__ double lerp_ref(double t, double a, double b) { return a + t * (b - a); }
+
+__global__ void k_resample(ResampleParams p) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = p.N, D = p.D;
+  if (p.status && p.status[b] != 0) {
+    if (i == 0) p.count[b] = 0;
+    return;
+  }
+  const double *tm = p.time + (size_t)b * N;
+  const double start = p.start_sec[b];
+  const double duration = tm[N - 1] - start;
+  const int M = (int)(ceil(duration / p.time_step) + 1);
+  if (i == 0) p.count[b] = M;
+  if (i >= M || i >= p.max_out) return;
+  const double t = start + p.time_step * i;
+  // first index in [0, N-2] with tm[index+1] > t, else N-1
+  int lower;
+  if (!(tm[N - 1] > t)) {
+    lower = N - 1;
+  } else {
+    int lo = 1, hi = N - 1;  // first j in [1, N-1] with tm[j] > t (exists: tm[N-1] > t)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (tm[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    lower = lo - 1;
+  }
+  const int upper = (N - 1 < lower + 1) ? N - 1 : lower + 1;
+  const double at = (fabs(tm[upper] - tm[lower]) < DBL_EPSILON)
+                        ? 0.5
+                        : (t - tm[lower]) / (tm[upper] - tm[lower]);
+  const size_t ob = (size_t)b * p.max_out + i;
+  const size_t kl = (size_t)b * N + lower, ku = (size_t)b * N + upper;
+  p.ot[ob] = t;
+  p.os[ob] = lerp_ref(at, p.s[kl], p.s[ku]);
+  p.osd[ob] = lerp_ref(at, p.sd[kl], p.sd[ku]);
+  p.osdd[ob] = lerp_ref(at, p.sdd[kl], p.sdd[ku]);
+  const bool last = (i == M - 1);
+  for (int d = 0; d < D; d++) {
+    const double am = p.amax[(size_t)b * D + d];
+    double vq, vqd, vqdd;
+    if (last) {
+      vq = p.q[((size_t)b * N + (N - 1)) * D + d];
+      vqd = 0.0; vqdd = 0.0;
+    } else {
+      vq = lerp_ref(at, p.q[kl * D + d], p.q[ku * D + d]);
+      vqd = lerp_ref(at, p.qd[kl * D + d], p.qd[ku * D + d]);
+      vqdd = lerp_ref(at, p.qdd[kl * D + d], p.qdd[ku * D + d]);
+      if (vqdd < -am) vqdd = -am;
+      if (vqdd > am) vqdd = am;
+    }
+    p.oq[ob * D + d] = vq;
+    p.oqd[ob * D + d] = vqd;
+    p.oqdd[ob * D + d] = vqdd;
+  }
+}
+
+}  // namespace tpamd

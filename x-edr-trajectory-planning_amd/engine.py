@@ -1,0 +1,338 @@
+"""ctypes binding of the engine's C-ABI (include/tpamd.h -> csrc/libtpamd.so).
+
+Plumbing only: device memory, streams and torch.distributed come from PyTorch;
+all computation happens in the hand-written HIP kernels behind the C-ABI. There
+is NO CPU fallback: if the shared library or a HIP device is missing, every
+entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libtpamd.so")
+_SOURCES = ["tpamd_capi.hip", "tpamd_kernels.h", "tpamd_device.h"]
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "tpamd.h")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
+               "-std=c++17"]
+
+PATH_STATUS = {
+    0: "ok", 2: "infeasible_bounds", 3: "s_range", 4: "sd_start_negative",
+    5: "lower_ge_upper", 6: "too_few_samples", 7: "no_connection", 8: "nan_sd2",
+    9: "nonzero_end", 10: "crit_index_zero",
+}
+
+KERNEL_SWEEP = 4
+
+
+class TpamdError(RuntimeError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    deps = [os.path.join(_CSRC, s) for s in _SOURCES] + [_HEADER]
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps)
+    if stale:
+        cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", _SO, os.path.join(_CSRC, "tpamd_capi.hip")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=_CSRC)
+    return _SO
+
+
+class _JointBatch(C.Structure):
+    _fields_ = [("num_paths", C.c_int32), ("num_dofs", C.c_int32), ("num_samples", C.c_int32),
+                ("num_points", C.c_int32), ("max_solver_loops", C.c_int32),
+                ("reserved", C.c_int32), ("constraint_safety", C.c_double)]
+
+
+class _JointInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "knots", "control_points", "max_velocity", "max_acceleration", "path_start", "delta",
+        "sd_start", "sdd_start", "time_start")]
+
+
+class _PathOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
+        "max_time_increment", "status")]
+
+
+class _RowsBatch(C.Structure):
+    _fields_ = [("num_paths", C.c_int32), ("num_samples", C.c_int32), ("num_rows", C.c_int32),
+                ("max_solver_loops", C.c_int32)]
+
+
+class _RowsInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "a", "b", "lower", "upper", "s_start", "s_end", "sd_start", "sdd_start", "time_start")]
+
+
+class _ResampleArgs(C.Structure):
+    _fields_ = ([("num_paths", C.c_int32), ("num_samples", C.c_int32), ("num_dofs", C.c_int32),
+                 ("max_out", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("time", "s", "sd", "sdd", "q", "qd", "qdd",
+                                           "max_acceleration", "start_sec")] +
+                [("time_step", C.c_double), ("status", C.c_void_p)] +
+                [(n, C.c_void_p) for n in ("out_time", "out_s", "out_sd", "out_sdd", "out_q",
+                                           "out_qd", "out_qdd", "count")])
+
+
+_LIB = None
+
+# every symbol include/tpamd.h declares
+ABI_SYMBOLS = [
+    "tpamd_engine_create", "tpamd_engine_destroy", "tpamd_version", "tpamd_error_string",
+    "tpamd_engine_reserve", "tpamd_engine_workspace_bytes", "tpamd_time_joint_paths_device",
+    "tpamd_time_joint_paths_host", "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
+    "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
+    "tpamd_debug_copy_boundary", "tpamd_profile_reset", "tpamd_profile_enable",
+    "tpamd_profile_mean_ms", "tpamd_profile_kernel_name", "tpamd_profile_num_kernels",
+]
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_SO):
+        raise TpamdError(
+            "libtpamd.so is not built (%s). Run __graft_entry__.build(); there is no CPU "
+            "fallback for the engine." % _SO)
+    L = C.CDLL(_SO)
+    vp, i = C.c_void_p, C.c_int
+    L.tpamd_engine_create.restype = i
+    L.tpamd_engine_create.argtypes = [i, C.POINTER(vp)]
+    L.tpamd_engine_destroy.argtypes = [vp]
+    L.tpamd_version.restype = i
+    L.tpamd_error_string.restype = C.c_char_p
+    L.tpamd_error_string.argtypes = [i]
+    L.tpamd_engine_reserve.restype = i
+    L.tpamd_engine_reserve.argtypes = [vp, i, i, i]
+    L.tpamd_engine_workspace_bytes.restype = C.c_size_t
+    L.tpamd_engine_workspace_bytes.argtypes = [vp]
+    L.tpamd_time_joint_paths_device.restype = i
+    L.tpamd_time_joint_paths_device.argtypes = [vp, C.POINTER(_JointBatch),
+                                                C.POINTER(_JointInputs),
+                                                C.POINTER(_PathOutputs), vp]
+    L.tpamd_time_joint_paths_host.restype = i
+    L.tpamd_time_joint_paths_host.argtypes = [vp, C.POINTER(_JointBatch),
+                                              C.POINTER(_JointInputs), C.POINTER(_PathOutputs)]
+    L.tpamd_optimize_rows_device.restype = i
+    L.tpamd_optimize_rows_device.argtypes = [vp, C.POINTER(_RowsBatch), C.POINTER(_RowsInputs),
+                                             C.POINTER(_PathOutputs), vp]
+    L.tpamd_optimize_rows_host.restype = i
+    L.tpamd_optimize_rows_host.argtypes = [vp, C.POINTER(_RowsBatch), C.POINTER(_RowsInputs),
+                                           C.POINTER(_PathOutputs)]
+    L.tpamd_find_max_sd2_host.restype = i
+    L.tpamd_find_max_sd2_host.argtypes = [vp, i, i] + [vp] * 7
+    L.tpamd_query_device.restype = i
+    L.tpamd_query_device.argtypes = [vp, i, i, i] + [vp] * 9 + [vp]
+    L.tpamd_resample_uniform_device.restype = i
+    L.tpamd_resample_uniform_device.argtypes = [vp, C.POINTER(_ResampleArgs), vp]
+    L.tpamd_debug_copy_boundary.restype = i
+    L.tpamd_debug_copy_boundary.argtypes = [vp, i, i] + [vp] * 6
+    L.tpamd_profile_reset.argtypes = [vp]
+    L.tpamd_profile_enable.argtypes = [vp, i]
+    L.tpamd_profile_mean_ms.restype = C.c_double
+    L.tpamd_profile_mean_ms.argtypes = [vp, i, C.POINTER(i)]
+    L.tpamd_profile_kernel_name.restype = C.c_char_p
+    L.tpamd_profile_kernel_name.argtypes = [i]
+    L.tpamd_profile_num_kernels.restype = i
+    _LIB = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise TpamdError("%s failed: %d (%s)" % (what, rc,
+                                                load_library().tpamd_error_string(rc).decode()))
+
+
+def _ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, np.ndarray):
+        assert t.flags["C_CONTIGUOUS"]
+        return t.ctypes.data
+    assert t.is_contiguous()
+    return t.data_ptr()
+
+
+class Engine:
+    """One engine per GPU (tpamd_engine_create/destroy)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.tpamd_engine_create(int(device), C.byref(h)), "tpamd_engine_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tpamd_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, num_paths, num_samples, num_rows):
+        _check(self._lib.tpamd_engine_reserve(self._h, num_paths, num_samples, num_rows),
+               "tpamd_engine_reserve")
+
+    @property
+    def workspace_bytes(self):
+        return self._lib.tpamd_engine_workspace_bytes(self._h)
+
+    # ------------------------------------------------------------ joint paths
+    def time_joint_paths(self, inputs, outputs, num_samples, safety=0.8, max_solver_loops=0,
+                         stream=None, host=False):
+        """inputs: dict with knots [B][P+3], control_points [B][P][D], max_velocity,
+        max_acceleration [B][D], path_start, delta, sd_start, time_start [B] (+ optional
+        sdd_start). outputs: dict with time, s, sd, sdd [B][N], status [B] int32 and optional
+        q, qd, qdd [B][N][D], last_extremal_index [B] int32, max_time_increment [B].
+        Torch CUDA tensors (host=False) or numpy arrays (host=True)."""
+        cp = inputs["control_points"]
+        B, P, D = cp.shape
+        bt = _JointBatch(B, D, int(num_samples), P, int(max_solver_loops), 0, float(safety))
+        ji = _JointInputs(*[_ptr(inputs.get(k)) for k in (
+            "knots", "control_points", "max_velocity", "max_acceleration", "path_start", "delta",
+            "sd_start", "sdd_start", "time_start")])
+        po = _PathOutputs(*[_ptr(outputs.get(k)) for k in (
+            "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
+            "max_time_increment", "status")])
+        if host:
+            _check(self._lib.tpamd_time_joint_paths_host(self._h, C.byref(bt), C.byref(ji),
+                                                         C.byref(po)),
+                   "tpamd_time_joint_paths_host")
+        else:
+            _check(self._lib.tpamd_time_joint_paths_device(self._h, C.byref(bt), C.byref(ji),
+                                                           C.byref(po), _stream_ptr(stream)),
+                   "tpamd_time_joint_paths_device")
+
+    # ------------------------------------------------------- constraint rows
+    def optimize_rows(self, inputs, outputs, max_solver_loops=0, stream=None, host=False):
+        a = inputs["a"]
+        B, N, Cn = a.shape
+        bt = _RowsBatch(B, N, Cn, int(max_solver_loops))
+        ri = _RowsInputs(*[_ptr(inputs.get(k)) for k in (
+            "a", "b", "lower", "upper", "s_start", "s_end", "sd_start", "sdd_start",
+            "time_start")])
+        po = _PathOutputs(*[_ptr(outputs.get(k)) for k in (
+            "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
+            "max_time_increment", "status")])
+        if host:
+            _check(self._lib.tpamd_optimize_rows_host(self._h, C.byref(bt), C.byref(ri),
+                                                      C.byref(po)), "tpamd_optimize_rows_host")
+        else:
+            _check(self._lib.tpamd_optimize_rows_device(self._h, C.byref(bt), C.byref(ri),
+                                                        C.byref(po), _stream_ptr(stream)),
+                   "tpamd_optimize_rows_device")
+
+    def find_max_sd2(self, a, b, lower, upper):
+        """Host numpy [num][C] -> (sd2max, sddmax, sd2zero) [num]."""
+        a, b, lower, upper = (np.ascontiguousarray(x, dtype=np.float64)
+                              for x in (a, b, lower, upper))
+        num, Cn = a.shape
+        o = [np.zeros(num) for _ in range(3)]
+        _check(self._lib.tpamd_find_max_sd2_host(self._h, num, Cn, _ptr(a), _ptr(b), _ptr(lower),
+                                                 _ptr(upper), _ptr(o[0]), _ptr(o[1]), _ptr(o[2])),
+               "tpamd_find_max_sd2_host")
+        return tuple(o)
+
+    def query(self, time, s, sd, status, t_query, out_s, out_sd, out_sdd, ok=None, stream=None):
+        B, N = time.shape
+        K = t_query.shape[1]
+        _check(self._lib.tpamd_query_device(self._h, B, N, K, _ptr(time), _ptr(s), _ptr(sd),
+                                            _ptr(status), _ptr(t_query), _ptr(out_s),
+                                            _ptr(out_sd), _ptr(out_sdd), _ptr(ok),
+                                            _stream_ptr(stream)), "tpamd_query_device")
+
+    def resample_uniform(self, sol, max_acceleration, start_sec, time_step, out, stream=None):
+        """sol: dict time,s,sd,sdd [B][N], q,qd,qdd [B][N][D], status. out: dict out_time..
+        [B][max_out], out_q.. [B][max_out][D], count [B] int32."""
+        B, N, D = sol["q"].shape
+        max_out = out["out_time"].shape[1]
+        args = _ResampleArgs(
+            B, N, D, max_out,
+            *[_ptr(sol[k]) for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd")],
+            _ptr(max_acceleration), _ptr(start_sec), float(time_step), _ptr(sol.get("status")),
+            *[_ptr(out[k]) for k in ("out_time", "out_s", "out_sd", "out_sdd", "out_q",
+                                     "out_qd", "out_qdd", "count")])
+        _check(self._lib.tpamd_resample_uniform_device(self._h, C.byref(args),
+                                                       _stream_ptr(stream)),
+               "tpamd_resample_uniform_device")
+
+    def debug_boundary(self, B, N):
+        arr = {k: np.zeros((B, N)) for k in ("sd2_max", "sdd_max", "sdd_min", "sd2_zero", "sd2")}
+        arr["type"] = np.zeros((B, N), dtype=np.uint8)
+        _check(self._lib.tpamd_debug_copy_boundary(
+            self._h, B, N, _ptr(arr["sd2_max"]), _ptr(arr["sdd_max"]), _ptr(arr["sdd_min"]),
+            _ptr(arr["sd2_zero"]), _ptr(arr["type"]), _ptr(arr["sd2"])),
+            "tpamd_debug_copy_boundary")
+        return arr
+
+    # ---------------------------------------------------------------- timing
+    def profile_enable(self, on=True):
+        self._lib.tpamd_profile_enable(self._h, 1 if on else 0)
+
+    def profile_reset(self):
+        self._lib.tpamd_profile_reset(self._h)
+
+    def profile_mean_ms(self, kernel_index):
+        n = C.c_int(0)
+        ms = self._lib.tpamd_profile_mean_ms(self._h, int(kernel_index), C.byref(n))
+        return ms, n.value
+
+    def profile_summary(self):
+        out = {}
+        for k in range(self._lib.tpamd_profile_num_kernels()):
+            ms, n = self.profile_mean_ms(k)
+            out[self._lib.tpamd_profile_kernel_name(k).decode()] = (ms, n)
+        return out
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if isinstance(stream, int):
+        return C.c_void_p(stream)
+    return C.c_void_p(stream.cuda_stream)
+
+
+def alloc_joint_outputs(B, N, D, device, with_q=True, with_derivs=True):
+    import torch
+    f = dict(dtype=torch.float64, device=device)
+    out = dict(time=torch.empty(B, N, **f), s=torch.empty(B, N, **f), sd=torch.empty(B, N, **f),
+               sdd=torch.empty(B, N, **f),
+               last_extremal_index=torch.zeros(B, dtype=torch.int32, device=device),
+               max_time_increment=torch.zeros(B, **f),
+               status=torch.full((B,), -1, dtype=torch.int32, device=device))
+    if with_q:
+        out["q"] = torch.empty(B, N, D, **f)
+    if with_derivs:
+        out["qd"] = torch.empty(B, N, D, **f)
+        out["qdd"] = torch.empty(B, N, D, **f)
+    return out
+
+
+def upload_joint_batch(batch, device):
+    import torch
+    keys = ("knots", "control_points", "vmax", "amax", "path_start", "delta", "sd_start",
+            "time_start")
+    t = {k: torch.from_numpy(np.ascontiguousarray(batch[k])).to(device) for k in keys}
+    return dict(knots=t["knots"], control_points=t["control_points"], max_velocity=t["vmax"],
+                max_acceleration=t["amax"], path_start=t["path_start"], delta=t["delta"],
+                sd_start=t["sd_start"], time_start=t["time_start"])
