@@ -1,0 +1,325 @@
+"""GPU parity tests: the HIP engine, called through its C-ABI, against the CPU
+oracle on the same inputs. fp64 everywhere; the north-star tolerance is 1e-6
+relative on t, s, sd, q. The kernels keep the reference's operation order and
+are built with -ffp-contract=off, so most comparisons are additionally held to
+bit-equality (flagged where they are)."""
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import scenarios
+from conftest import PKG_NAME
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6   # BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on an MI355X")
+    eng = importlib.import_module(PKG_NAME + ".engine")
+    syn = importlib.import_module(PKG_NAME + ".synthetic")
+    from oracle import tpo
+    return dict(torch=torch, eng=eng, syn=syn, tpo=tpo, E=eng.Engine(0), dev="cuda:0")
+
+
+def assert_close(got, ref, what):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape, what
+    scale = np.maximum(np.abs(ref), 1e-9)
+    err = np.max(np.abs(got - ref) / scale) if got.size else 0.0
+    assert err <= REL_TOL, "%s: max rel err %.3e" % (what, err)
+
+
+def solve_joint(env, batch, N, D, **kw):
+    torch, eng, E = env["torch"], env["eng"], env["E"]
+    B = batch["control_points"].shape[0]
+    inp = eng.upload_joint_batch(batch, env["dev"])
+    out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    E.time_joint_paths(inp, out, N, **kw)
+    torch.cuda.synchronize()
+    return inp, out
+
+
+def oracle_joint(env, batch, N, **kw):
+    return env["tpo"].time_joint_batch(batch["knots"], batch["control_points"], batch["vmax"],
+                                       batch["amax"], batch["path_start"], batch["delta"], N,
+                                       sd_start=batch["sd_start"], time_start=batch["time_start"],
+                                       nthreads=8, **kw)
+
+
+# ---------------------------------------------------------------------- LP
+def test_lp_literal_and_random(env, golden_dir):
+    E, tpo = env["E"], env["tpo"]
+    lp = json.load(open(os.path.join(golden_dir, "lp_regression.json")))
+    for c in lp["cases"]:
+        g = E.find_max_sd2(np.array([c["a"]]), np.array([c["b"]]), np.array([c["lower"]]),
+                           np.array([c["upper"]]))
+        o = tpo.find_max_sd2_simplex(c["a"], c["b"], c["lower"], c["upper"])
+        r = tpo.find_max_sd2_bruteforce(c["a"], c["b"], c["lower"], c["upper"])
+        assert (g[0][0], g[1][0], g[2][0]) == o            # bit-exact vs oracle
+        assert abs(g[0][0] - r[0]) <= 1e-8 and abs(g[2][0] - r[2]) <= 1e-8   # reference's check
+    rng = np.random.default_rng(0)
+    for Cn in (2, 3, 7, 14, 30, 33, 50, 64):
+        n = 3000
+        A = rng.uniform(-100, 100, (n, Cn)); Bm = rng.uniform(-100, 100, (n, Cn))
+        lo = rng.uniform(-10, 0, (n, Cn)); hi = rng.uniform(0, 10, (n, Cn))
+        g = E.find_max_sd2(A, Bm, lo, hi)
+        o = np.array([tpo.find_max_sd2_simplex(A[i], Bm[i], lo[i], hi[i]) for i in range(n)])
+        for k in range(3):
+            np.testing.assert_array_equal(g[k], o[:, k])   # bit-exact
+        r = np.array([tpo.find_max_sd2_bruteforce(A[i], Bm[i], lo[i], hi[i]) for i in range(300)])
+        for k in range(3):
+            assert np.max(np.abs(g[k][:300] - r[:, k])) <= 1e-8
+    # degenerate sets: all-zero rows and unbounded problems saturate at kMaxSd2
+    z = np.zeros((2, 14))
+    g = E.find_max_sd2(z, z, -np.ones((2, 14)), np.ones((2, 14)))
+    assert g[0][0] == 1e6 and g[1][0] == 0.0 and g[2][0] == 1e6
+
+
+# ------------------------------------------------ rows mode: reference scenarios
+def _rows_solve(env, rows_list, s0, s1, sd0, max_loops=0, sdd0=None):
+    E = env["E"]
+    A = np.stack([r[0] for r in rows_list]); Bm = np.stack([r[1] for r in rows_list])
+    lo = np.stack([r[2] for r in rows_list]); hi = np.stack([r[3] for r in rows_list])
+    Bn, n, _ = A.shape
+    inp = dict(a=np.ascontiguousarray(A), b=np.ascontiguousarray(Bm),
+               lower=np.ascontiguousarray(lo), upper=np.ascontiguousarray(hi),
+               s_start=np.full(Bn, s0, float), s_end=np.full(Bn, s1, float),
+               sd_start=np.full(Bn, sd0, float),
+               sdd_start=np.zeros(Bn) if sdd0 is None else np.full(Bn, sdd0, float),
+               time_start=np.zeros(Bn))
+    out = dict(time=np.zeros((Bn, n)), s=np.zeros((Bn, n)), sd=np.zeros((Bn, n)),
+               sdd=np.zeros((Bn, n)), last_extremal_index=np.zeros(Bn, np.int32),
+               max_time_increment=np.zeros(Bn), status=np.full(Bn, -1, np.int32))
+    E.optimize_rows(inp, out, max_solver_loops=max_loops, host=True)
+    return out
+
+
+CASES = scenarios.all_cases()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_rows_mode_scenarios(env, case):
+    tpo, E = env["tpo"], env["E"]
+    name, rows, s0, s1, sd0, meta = case
+    n, c = rows[0].shape
+    p = tpo.Profile(n, c)
+    assert p.setup(*rows, s0, s1, sd0, 0.0, 0.0) == 0 and p.optimize() == 0
+    out = _rows_solve(env, [rows], s0, s1, sd0)
+    assert out["status"][0] == 0
+    bd = E.debug_boundary(1, n)
+    # stage-wise, bit-exact: boundary curve, classification, solution
+    np.testing.assert_array_equal(bd["sd2_max"][0], p.sd2_max)
+    np.testing.assert_array_equal(bd["sdd_max"][0], p.sdd_max_for_sd2_max)
+    np.testing.assert_array_equal(bd["sdd_min"][0], p.sdd_min_for_sd2_max)
+    np.testing.assert_array_equal(bd["type"][0], p.boundary_type)
+    for k, ref in (("time", p.time), ("s", p.s), ("sd", p.sd), ("sdd", p.sdd)):
+        np.testing.assert_array_equal(out[k][0], ref)
+        assert_close(out[k][0], ref, k)
+    assert out["last_extremal_index"][0] == p.last_extremal_index
+    assert out["max_time_increment"][0] == p.max_time_increment
+    # and the reference's own property checks hold for the GPU result
+    assert scenarios.max_violation(meta, out["s"][0], out["sd"][0], out["sdd"][0]) < tpo.KTINY
+
+
+def test_rows_mode_setup_failures_and_mixed_batch(env):
+    rows = scenarios.scalar_straight(30, 0.5, 1.0)
+    A, Bm, lo, hi = rows
+    bad_all = (A, Bm, lo, np.where(np.arange(30)[:, None] == 3, lo - 1.0, hi))
+    bad_one = (A, Bm, lo, hi.copy())
+    bad_one[3][3, 0] = lo[3, 0]
+    out = _rows_solve(env, [rows, bad_all, bad_one, rows], 0.0, 1.0, 0.0)
+    assert list(out["status"]) == [0, 2, 5, 0]          # a failed path does not abort the batch
+    np.testing.assert_array_equal(out["time"][0], out["time"][3])
+    assert _rows_solve(env, [rows], 1.0, 1.0, 0.0)["status"][0] == 3
+    assert _rows_solve(env, [rows], 0.0, 1.0, -0.5)["status"][0] == 4
+    assert _rows_solve(env, [bad_all], 1.0, 1.0, 0.0)["status"][0] == 2   # bounds checked first
+
+
+def test_rows_mode_loop_limit_matches_oracle(env):
+    # with too few solver loops the reference ends with NaNs in sd2 ("No solution found")
+    tpo = env["tpo"]
+    b = env["syn"].make_joint_batch(2, 7, 500)
+    rows_list, refs = [], []
+    for i in range(2):
+        q, q1, q2 = tpo.joint_sample_path(b["knots"][i], b["control_points"][i], 0.0,
+                                          b["delta"][i], 500)
+        rows = tpo.joint_constraint_setup(q1, q2, b["vmax"][i], b["amax"][i])
+        p = tpo.Profile(500, 14)
+        p.set_max_loops(3)
+        p.setup(*rows, 0.0, b["delta"][i] * 499)
+        refs.append(p.optimize())
+        rows_list.append(rows)
+    # paths differ in s_end: solve one at a time
+    for i in range(2):
+        out = _rows_solve(env, [rows_list[i]], 0.0, b["delta"][i] * 499, 0.0, max_loops=3)
+        assert out["status"][0] == refs[i] and refs[i] != 0
+
+
+# -------------------------------------------------------- joint mode vs oracle
+@pytest.mark.parametrize("D,N,B", [(7, 500, 48), (7, 2000, 32), (6, 2000, 16), (14, 1000, 16),
+                                   (3, 1000, 8), (1, 64, 4), (16, 300, 4), (7, 3, 2), (7, 4096, 2)])
+def test_joint_mode_matches_oracle(env, D, N, B):
+    b = env["syn"].make_joint_batch(B, D, N)
+    ref = oracle_joint(env, b, N)
+    _, out = solve_joint(env, b, N, D)
+    st = out["status"].cpu().numpy()
+    np.testing.assert_array_equal(st, ref["status"])
+    ok = st == 0
+    assert ok.sum() >= B // 2
+    np.testing.assert_array_equal(out["last_extremal_index"].cpu().numpy()[ok],
+                                  ref["last_extremal_index"][ok])
+    for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+        g = out[k].cpu().numpy()[ok]
+        r = ref["t" if k == "time" else k][ok]
+        assert_close(g, r, k)
+        np.testing.assert_array_equal(g, r)      # bit-exact
+
+
+def test_joint_mode_start_velocity_time_offset_and_padding(env):
+    # sd_start > 0, time_start != 0, path_start > 0 and a horizon that runs past the spline end
+    syn, tpo = env["syn"], env["tpo"]
+    D, N, B = 7, 800, 12
+    b = syn.make_joint_batch(B, D, N)
+    b["time_start"] = np.linspace(0.0, 50.0, B)
+    b["sd_start"] = np.where(np.arange(B) % 3 == 0, 0.05, 0.0)
+    b["path_start"] = np.where(np.arange(B) % 2 == 0, 0.0, 0.37)
+    b["delta"] = b["delta"] * np.where(np.arange(B) % 4 == 1, 1.2, 1.0)   # overshoots the end
+    ref = oracle_joint(env, b, N)
+    _, out = solve_joint(env, b, N, D)
+    st = out["status"].cpu().numpy()
+    np.testing.assert_array_equal(st, ref["status"])
+    ok = st == 0
+    assert ok.any()
+    for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+        np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
+
+
+def test_joint_mode_bad_limits_fail_per_path(env):
+    syn = env["syn"]
+    b = syn.make_joint_batch(6, 7, 300)
+    b["amax"][1, :] = 0.0          # every acceleration row lower == upper, but velocity rows fine
+    b["vmax"][2, :] = 0.0
+    b["amax"][2, :] = 0.0          # every row degenerate -> infeasible bounds
+    b["sd_start"][3] = -1.0
+    b["delta"][4] = 0.0            # s_start == s_end
+    ref = oracle_joint(env, b, 300)
+    _, out = solve_joint(env, b, 300, 7)
+    st = out["status"].cpu().numpy()
+    np.testing.assert_array_equal(st, ref["status"])
+    assert list(st[1:5]) == [5, 2, 4, 3] and st[0] == 0 and st[5] == 0
+
+
+def test_host_buffer_entry_point_equals_device_entry_point(env):
+    syn, E = env["syn"], env["E"]
+    D, N, B = 7, 500, 8
+    b = syn.make_joint_batch(B, D, N)
+    _, out = solve_joint(env, b, N, D)
+    inp = dict(knots=b["knots"], control_points=b["control_points"], max_velocity=b["vmax"],
+               max_acceleration=b["amax"], path_start=b["path_start"], delta=b["delta"],
+               sd_start=b["sd_start"], time_start=b["time_start"])
+    hout = dict(time=np.zeros((B, N)), s=np.zeros((B, N)), sd=np.zeros((B, N)),
+                sdd=np.zeros((B, N)), q=np.zeros((B, N, D)), qd=np.zeros((B, N, D)),
+                qdd=np.zeros((B, N, D)), last_extremal_index=np.zeros(B, np.int32),
+                max_time_increment=np.zeros(B), status=np.full(B, -1, np.int32))
+    E.time_joint_paths(inp, hout, N, host=True)
+    for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd", "status", "last_extremal_index"):
+        np.testing.assert_array_equal(hout[k], out[k].cpu().numpy())
+
+
+# ------------------------------------------------------- query and resample
+def test_query_and_resample_match_oracle(env):
+    torch, syn, tpo, E = env["torch"], env["syn"], env["tpo"], env["E"]
+    D, N, B, K = 7, 600, 6, 257
+    b = syn.make_joint_batch(B, D, N)
+    inp, out = solve_joint(env, b, N, D)
+    t = out["time"].cpu().numpy()
+    rng = np.random.default_rng(5)
+    tq = np.sort(rng.uniform(-0.5, t[:, -1:] + 0.5, (B, K)), axis=1)
+    tq[:, 10] = t[:, 37]           # exactly on a sample
+    tq_d = torch.from_numpy(tq).to(env["dev"])
+    qs, qsd, qsdd = (torch.empty(B, K, dtype=torch.float64, device=env["dev"]) for _ in range(3))
+    ok = torch.zeros(B, K, dtype=torch.int32, device=env["dev"])
+    E.query(out["time"], out["s"], out["sd"], out["status"], tq_d, qs, qsd, qsdd, ok)
+    torch.cuda.synchronize()
+    for i in range(B):
+        q_, q1, q2 = tpo.joint_sample_path(b["knots"][i], b["control_points"][i], 0.0,
+                                           b["delta"][i], N)
+        rows = tpo.joint_constraint_setup(q1, q2, b["vmax"][i], b["amax"][i])
+        p = tpo.Profile(N, 2 * D)
+        p.set_max_loops(10 * N)
+        assert p.setup(*rows, 0.0, b["delta"][i] * (N - 1)) == 0 and p.optimize() == 0
+        ref = np.array([p.query(x)[1:] for x in tq[i]])
+        np.testing.assert_array_equal(qs[i].cpu().numpy(), ref[:, 0])
+        np.testing.assert_array_equal(qsd[i].cpu().numpy(), ref[:, 1])
+        np.testing.assert_array_equal(qsdd[i].cpu().numpy(), ref[:, 2])
+    assert int(ok.min()) == 1
+
+    # resample (path_timing_trajectory.cc:755-783); 4 ms step as the reference's planner tests
+    dt = 0.004
+    start = np.zeros(B)
+    counts_ref = [tpo.resample_uniform(t[i], *[out[k][i].cpu().numpy() for k in
+                                               ("s", "sd", "sdd", "q", "qd", "qdd")],
+                                       0.0, dt, b["amax"][i]) for i in range(B)]
+    max_out = max(len(r[0]) for r in counts_ref) + 3
+    f = dict(dtype=torch.float64, device=env["dev"])
+    ro = dict(out_time=torch.zeros(B, max_out, **f), out_s=torch.zeros(B, max_out, **f),
+              out_sd=torch.zeros(B, max_out, **f), out_sdd=torch.zeros(B, max_out, **f),
+              out_q=torch.zeros(B, max_out, D, **f), out_qd=torch.zeros(B, max_out, D, **f),
+              out_qdd=torch.zeros(B, max_out, D, **f),
+              count=torch.zeros(B, dtype=torch.int32, device=env["dev"]))
+    E.resample_uniform(out, inp["max_acceleration"], torch.from_numpy(start).to(env["dev"]), dt, ro)
+    torch.cuda.synchronize()
+    cnt = ro["count"].cpu().numpy()
+    for i in range(B):
+        r = counts_ref[i]
+        M = len(r[0])
+        assert cnt[i] == M
+        for k, ref in zip(("out_time", "out_s", "out_sd", "out_sdd", "out_q", "out_qd", "out_qdd"), r):
+            np.testing.assert_array_equal(ro[k][i, :M].cpu().numpy(), ref)
+        np.testing.assert_array_equal(ro["out_q"][i, M - 1].cpu().numpy(), out["q"][i, -1].cpu().numpy())
+        assert float(ro["out_qd"][i, M - 1].abs().max()) == 0.0
+
+
+# ---------------------------------------------- BASELINE-size batch: properties
+def test_config2_full_size_properties(env):
+    """Config 2 of BASELINE.json (1024 paths, 7 dof, 2000 samples): size-independent
+    properties on every path, bit-parity with the oracle on a strided subset."""
+    torch, syn, tpo = env["torch"], env["syn"], env["tpo"]
+    D, N, B = 7, 2000, 1024
+    b = syn.make_joint_batch(B, D, N)
+    inp, out = solve_joint(env, b, N, D)
+    st = out["status"].cpu().numpy()
+    assert (st == 0).all()
+    t = out["time"].cpu().numpy(); s = out["s"].cpu().numpy()
+    sd = out["sd"].cpu().numpy(); sdd = out["sdd"].cpu().numpy()
+    qd = out["qd"].cpu().numpy(); qdd = out["qdd"].cpu().numpy(); q = out["q"].cpu().numpy()
+    assert np.isfinite(t).all() and np.isfinite(sd).all() and np.isfinite(sdd).all()
+    assert (np.diff(t, axis=1) >= 0).all() and (t[:, 0] == 0).all()
+    assert (sd[:, -1] == 0).all() and (sd[:, 0] == 0).all() and (sd >= 0).all()
+    assert (s[:, 0] == 0).all()
+    np.testing.assert_array_equal(s[:, -1], b["delta"] * (N - 1))
+    # joint limits with the 0.8 safety factor (timeable_path.h:80): |qd| <= 0.8 vmax, |qdd| <= amax
+    assert (np.abs(qd) <= 0.8 * b["vmax"][:, None, :] * (1 + 1e-9) + 1e-12).all()
+    assert (np.abs(qdd) <= b["amax"][:, None, :]).all()
+    np.testing.assert_allclose(q[:, 0], b["control_points"][:, 0], atol=1e-12)
+    np.testing.assert_allclose(q[:, -1], b["control_points"][:, -1], atol=1e-9)
+    # a time-optimal profile rides a velocity limit on a sizeable share of the samples
+    vact = np.abs(qd) >= 0.8 * b["vmax"][:, None, :] * (1 - 1e-6)
+    sel = slice(0, B, 37)
+    ref = tpo.time_joint_batch(b["knots"][sel], b["control_points"][sel], b["vmax"][sel],
+                               b["amax"][sel], b["path_start"][sel], b["delta"][sel], N, nthreads=8)
+    for k, g in (("t", t), ("s", s), ("sd", sd), ("sdd", sdd), ("q", q), ("qd", qd), ("qdd", qdd)):
+        np.testing.assert_array_equal(g[sel], ref[k])
+    assert vact.any(axis=2).mean() > 0.2
+    # a checksum of checksums so that a silent change of any output shows up
+    chk = float(np.sum(t[:, -1]) + np.sum(sd * 1e-3) + np.sum(q * 1e-6))
+    chk_ref_subset = float(np.sum(ref["t"][:, -1]))
+    assert abs(np.sum(t[sel, -1]) - chk_ref_subset) == 0.0 and np.isfinite(chk)
