@@ -207,6 +207,12 @@ int tpamd_debug_copy_boundary(tpamd_engine *engine, int num_paths, int num_sampl
                               double *sd2_max, double *sdd_max, double *sdd_min,
                               double *sd2_zero, uint8_t *type, double *sd2);
 
+/* Diagnostic builds (-DTPAMD_DIAG) only: per-path cycle counters of the sweep kernel,
+ * [B][16] int64 (0 fwd extremals, 1 bwd extremals, 2 critical-point search, 3 tail,
+ * 4 FindSdd steps, 5 whole loop, 8/9 boundary-following steps fwd/bwd, 10/11 FindSdd
+ * steps fwd/bwd). The product build leaves them zero. */
+int tpamd_debug_copy_diag(tpamd_engine *engine, int num_paths, long long *out);
+
 /* Name and average-launch bookkeeping of the dominant kernel for bench.py:
  * records HIP events around the sweep kernel of every solve on its own stream.
  * Returns the mean duration in milliseconds over the launches since the last

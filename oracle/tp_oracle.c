@@ -700,12 +700,22 @@ done:
   free(act);
 }
 
+/* Debug counters (single-threaded use only): [0] forward steps, [1] backward steps,
+ * [2] boundary-exceed validity checks, [3] intersection fix-ups, [4] critical-point
+ * searches, [5] samples scanned by those searches. */
+static long long g_counters[8];
+void tpo_debug_counters(long long *out, int reset) {
+  for (int i = 0; i < 8; i++) { out[i] = g_counters[i]; if (reset) g_counters[i] = 0; }
+}
+
 /* .cc:753-767 */
 static void forward_step(const tpo_profile *p, int index, double sd2, double *sdd, double *sd2next) {
+  g_counters[0]++;
   *sdd = sdd_max_at(p, index, sd2);
   *sd2next = sd2 + 2.0 * p->ds * (*sdd);
 }
 static void backward_step(const tpo_profile *p, int index, double sd2, double *sdd, double *sd2prev) {
+  g_counters[1]++;
   *sdd = sdd_min_at(p, index, sd2);
   *sd2prev = sd2 - 2.0 * p->ds * (*sdd);
 }
@@ -784,6 +794,7 @@ int tpo_profile_calculate_boundary(tpo_profile *p) {
 /* .cc:722-751 */
 static void sdd_at_intersection(tpo_profile *p, int index) {
   const int N = p->N;
+  g_counters[3]++;
   double cand[3]; int n = 0;
   if (index > 0 && index < N - 1) cand[n++] = 0.25 / p->ds * (p->sd2[index + 1] - p->sd2[index - 1]);
   if (index < N - 1) cand[n++] = 0.5 / p->ds * (p->sd2[index + 1] - p->sd2[index]);
@@ -815,6 +826,7 @@ static int add_forward_extremal(tpo_profile *p, int idx_lo) {
     if (sd2tmp > p->sd2_max[idx + 1]) {
       const double sdd_bound = 0.5 * (p->sd2_max[idx + 1] - p->sd2[idx]) / p->ds;
       const int deriv_invalid = !derivs_valid(p, idx, sdd_bound, p->sd2_max[idx]);
+      g_counters[2]++;
       const int type_invalid = p->type[idx + 1] & TPO_BND_SINK;
       if (type_invalid || deriv_invalid) return idx;
       sd2tmp = p->sd2_max[idx + 1];
@@ -851,6 +863,7 @@ static int add_backward_extremal(tpo_profile *p, int idx_hi) {
     if (sd2tmp > p->sd2_max[idx - 1]) {
       const double sdd_bound = 0.5 * (p->sd2[idx] - p->sd2_max[idx - 1]) / p->ds;
       const int deriv_invalid = !derivs_valid(p, idx, sdd_bound, p->sd2[idx]);
+      g_counters[2]++;
       const int type_invalid = p->type[idx - 1] & TPO_BND_SOURCE;
       const int is_connecting = (idx_hi != (N - 1));
       if ((type_invalid || deriv_invalid) && !is_connecting) return idx;
@@ -870,7 +883,9 @@ static int add_backward_extremal(tpo_profile *p, int idx_hi) {
 /* .cc:697-720 */
 static int next_critical_point(const tpo_profile *p, int idx_lo, int idx_hi) {
   int crit = -1;
+  g_counters[4]++;
   for (int idx = idx_lo + 1; idx <= idx_hi; idx++) {
+    g_counters[5]++;
     if (crit < 0) {
       if ((p->type[idx] & TPO_BND_SOURCE) || (p->type[idx] & TPO_BND_TRAJECTORY)) crit = idx;
     } else {

@@ -165,6 +165,9 @@ double tpo_find_sdd_max(const double *A, const double *B, const double *lower,
 double tpo_find_sdd_min(const double *A, const double *B, const double *lower,
                         const double *upper, int C, double sd2);
 
+/* Debug counters of the sweep (single-threaded use only); see tp_oracle.c. */
+void tpo_debug_counters(long long *out8, int reset);
+
 /* ------------------------------------------------- planner epilogue/resample */
 
 /* path_timing_trajectory.cc:458-472 : qd = q1*sd ; qdd = clamp(q1*sdd + q2*sd^2) */

@@ -6,11 +6,13 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "tpamd_kernels.h"
+#include "tpamd_sweep_joint.h"
 
 using namespace tpamd;
 
@@ -61,6 +63,7 @@ struct tpamd_engine {
   Workspace ws{};
   int last_B = 0, last_N = 0;
   bool profile = false;
+  bool force_generic = false;  // TPAMD_FORCE_GENERIC=1: A/B the specialised kernels
   std::vector<EventPair> events;
 };
 
@@ -85,7 +88,7 @@ size_t carve_workspace(char *base, int B, int N, int C, Workspace *ws) {
   w.delta = (double *)take(nb * 8);
   w.err_bits = (uint32_t *)take(nb * 4);
   w.lim = (double *)take(nb * 2 * C * 8);
-  w.q12 = (double *)take(ns * C * 8);
+  w.q12 = (double *)take(ns * (C + 2) * 8);
   w.m0 = (double *)take(ns * 8);
   w.z0 = (double *)take(ns * 8);
   w.X0 = (double *)take(ns * 8);
@@ -100,6 +103,7 @@ size_t carve_workspace(char *base, int B, int N, int C, Workspace *ws) {
   w.Y = (double *)take(ns * 8);
   w.type = (uint8_t *)take(ns);
   w.sd2 = (double *)take(ns * 8);
+  w.diag = (long long *)take(nb * 16 * 8);
   if (ws) *ws = w;
   return off;
 }
@@ -166,6 +170,38 @@ void configure_kernels_once() {
   allow_big_lds(k_lp_rows<2>);
   allow_big_lds(k_sweep<JointSource>);
   allow_big_lds(k_sweep<GenericSource>);
+  allow_big_lds(k_sweep_joint<6>);
+  allow_big_lds(k_sweep_joint<7>);
+  allow_big_lds(k_sweep_joint<14>);
+}
+
+// The sweep launch: joint-space batches with D in {6, 7, 14} (the BASELINE.json
+// configurations) take the specialised kernel, everything else the generic one.
+template <class Source>
+void launch_sweep(hipStream_t st, int B, int N, int max_loops, const Source &src,
+                  const Workspace &ws, const tpamd_path_outputs *out, bool force_generic) {
+  const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
+  hipLaunchKernelGGL((k_sweep<Source>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
+                     out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
+                     out->max_time_increment, out->status);
+}
+
+template <>
+void launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
+                               const Workspace &ws, const tpamd_path_outputs *out,
+                               bool force_generic) {
+  const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
+#define TPAMD_LAUNCH_JOINT(DD)                                                                  \
+  hipLaunchKernelGGL((k_sweep_joint<DD>), dim3(B), dim3(64), sweep_joint_lds_bytes<DD>(N), st,  \
+                     N, max_loops, src, ws, out->time, out->s, out->sd, out->sdd,               \
+                     out->last_extremal_index, out->max_time_increment, out->status)
+  if (!force_generic && src.D == 7) { TPAMD_LAUNCH_JOINT(7); return; }
+  if (!force_generic && src.D == 6) { TPAMD_LAUNCH_JOINT(6); return; }
+  if (!force_generic && src.D == 14) { TPAMD_LAUNCH_JOINT(14); return; }
+#undef TPAMD_LAUNCH_JOINT
+  hipLaunchKernelGGL((k_sweep<JointSource>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
+                     out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
+                     out->max_time_increment, out->status);
 }
 
 // Shared tail: detect -> final -> sweep (-> epilogue in joint mode).
@@ -184,10 +220,7 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
   }
   {
     Timer t(e, st, KI_SWEEP);
-    const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
-    hipLaunchKernelGGL((k_sweep<Source>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
-                       out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
-                       out->max_time_increment, out->status);
+    launch_sweep(st, B, N, max_loops, src, ws, out, e->force_generic);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -232,6 +265,10 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
   tpamd_engine *e = new (std::nothrow) tpamd_engine();
   if (!e) return TPAMD_E_HIP;
   e->device = device_ordinal;
+  {
+    const char *fg = std::getenv("TPAMD_FORCE_GENERIC");
+    e->force_generic = fg && fg[0] == '1';
+  }
   configure_kernels_once();
   *out = e;
   return 0;
@@ -282,8 +319,8 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   }
   {
     Timer t(e, st, KI_SAMPLE_LP);
-    const int tpb = (C <= 14) ? 256 : (C <= 28 ? 128 : 64);
-    const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)C * tpb) * 8;
+    const int tpb = (C <= 28) ? 256 : 128;
+    const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)D * tpb) * 8;
     if (lds > 160 * 1024) return TPAMD_E_UNSUPPORTED;
     hipLaunchKernelGGL((k_sample_lp_joint<1>), dim3((N + tpb - 1) / tpb, B), dim3(tpb), lds, st,
                        N, D, P, in->knots, in->control_points, out->q, ws);
@@ -294,7 +331,7 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   if (rc) return rc;
   if (out->qd || out->qdd) {
     Timer t(e, st, KI_EPILOGUE);
-    const size_t total = (size_t)B * N;
+    const size_t total = (size_t)B * N * D;
     hipLaunchKernelGGL(k_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, N,
                        D, ws.q12, out->sd, out->sdd, in->max_acceleration, out->status, out->qd,
                        out->qdd);
@@ -544,8 +581,19 @@ int tpamd_debug_copy_boundary(tpamd_engine *e, int B, int N, double *sd2_max, do
   if (sdd_max) HIPCHK(hipMemcpy(sdd_max, e->ws.X, n * 8, hipMemcpyDeviceToHost));
   if (sdd_min) HIPCHK(hipMemcpy(sdd_min, e->ws.Y, n * 8, hipMemcpyDeviceToHost));
   if (sd2_zero) HIPCHK(hipMemcpy(sd2_zero, e->ws.z0, n * 8, hipMemcpyDeviceToHost));
-  if (type) HIPCHK(hipMemcpy(type, e->ws.type, n, hipMemcpyDeviceToHost));
+  if (type) {
+    HIPCHK(hipMemcpy(type, e->ws.type, n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) type[i] &= kBndTypeMask;  // drop the engine-internal cache bit
+  }
   if (sd2) HIPCHK(hipMemcpy(sd2, e->ws.sd2, n * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int tpamd_debug_copy_diag(tpamd_engine *e, int B, long long *out) {
+  if (!e || !out || B != e->last_B) return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, e->ws.diag, (size_t)B * 16 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -18,6 +18,9 @@ constexpr double kMaxSd2 = 1e6;
 
 // Boundary classification, time_optimal_path_timing.h:226-231
 enum : uint8_t { kBndNone = 0, kBndSource = 1, kBndSink = 2, kBndTrajectory = 4 };
+// engine-internal cache bit in the type byte (see k_boundary_final); masked out of every
+// comparison the reference makes and of the debug copy
+enum : uint8_t { kBndEqualsZ00 = 8, kBndTypeMask = 7 };
 
 // setup error bits (resolved to TPAMD_PATH_* in the reference's order of checks)
 enum : uint32_t {
@@ -57,18 +60,35 @@ struct LdsRows {
   __device__ __forceinline__ double hi(int c) const { return HI[c * lim_stride]; }
 };
 
+// Joint-space rows of this thread's sample with only q' and q'' staged in LDS
+// ([d][thread]); the velocity rows (A = 0, B = q'^2) are formed on access and the
+// per-path limits are shared by the block.
+struct LdsRowsJoint {
+  const double *Q1, *Q2;          // already offset by the thread index
+  const double *lim_lo, *lim_hi;  // [2D]
+  int stride, D;
+  __device__ __forceinline__ double a(int c) const { return c < D ? Q1[c * stride] : 0.0; }
+  __device__ __forceinline__ double b(int c) const {
+    if (c < D) return Q2[c * stride];
+    const double v = Q1[(c - D) * stride];
+    return v * v;
+  }
+  __device__ __forceinline__ double lo(int c) const { return lim_lo[c]; }
+  __device__ __forceinline__ double hi(int c) const { return lim_hi[c]; }
+};
+
 // Rows of a joint-space sample computed on the fly from q' and q'' in global
 // memory (timeable_path_joint_spline.cc:320-343): rows 0..D-1 are the
 // acceleration rows (A = q', B = q''), rows D..2D-1 the velocity rows
 // (A = 0, B = q'^2). lim_lo / lim_hi are the per-path limits [2D].
 struct JointRowsAt {
-  const double *q12;  // &q1q2[sample][0]: q'[0..D) then q''[0..D)
+  const double *q12;  // &q12[sample][0]: interleaved pairs (q'[d], q''[d]), d = 0..D-1
   const double *lim_lo, *lim_hi;
   int D;
-  __device__ __forceinline__ double a(int c) const { return c < D ? q12[c] : 0.0; }
+  __device__ __forceinline__ double a(int c) const { return c < D ? q12[2 * c] : 0.0; }
   __device__ __forceinline__ double b(int c) const {
-    if (c < D) return q12[D + c];
-    const double v = q12[c - D];
+    if (c < D) return q12[2 * c + 1];
+    const double v = q12[2 * (c - D)];
     return v * v;
   }
   __device__ __forceinline__ double lo(int c) const { return lim_lo[c]; }
@@ -110,6 +130,52 @@ __device__ void find_sdd_both(const R &r, int C, double sd2, double *sdd_max, do
         if (((sddi > smax) || (sddi < smin)) && rows_valid(r, C, sddi, sd2)) {
           if (sddi > smax) smax = sddi;
           if (sddi < smin) smin = sddi;
+        }
+      }
+    }
+  }
+  if (smax == -DBL_MAX) smax = 0;
+  if (smin == DBL_MAX) smin = 0;
+  *sdd_max = smax;
+  *sdd_min = smin;
+}
+
+// FindSddMax/FindSddMin for rows with the joint-space structure
+// (timeable_path_joint_spline.cc:320-343): rows D..2D-1 have A = 0, so they produce no
+// candidates (.cc:650) and, for a finite candidate, their validity test
+// v = 0*sdd + B*sd2 does not involve the candidate: it is evaluated once. A non-finite
+// candidate is never selected by the reference either (an infinite one violates its
+// own row, whose |A| >= kTiny; a NaN one fails "sddi > sdd"), so skipping them keeps
+// the result identical to find_sdd_both on the same rows.
+template <class R>
+__device__ void find_sdd_both_joint(const R &r, int D, double sd2, double *sdd_max,
+                                    double *sdd_min) {
+  double smax = -DBL_MAX, smin = DBL_MAX;
+  bool vel_ok = true;
+  for (int j = D; j < 2 * D; j++) {
+    const double v = r.b(j) * sd2;
+    if (v + kTiny < r.lo(j) || v - kTiny > r.hi(j)) vel_ok = false;
+  }
+  if (vel_ok) {
+    for (int i = 0; i < D; i++) {
+      const double A = r.a(i);
+      if (!is_tiny(A)) {
+        const double bs = r.b(i) * sd2;
+        for (int w = 0; w < 2; w++) {
+          const double lim = w ? r.hi(i) : r.lo(i);
+          const double sddi = (lim - bs) / A;
+          if (!(fabs(sddi) <= DBL_MAX)) continue;
+          if ((sddi > smax) || (sddi < smin)) {
+            bool ok = true;
+            for (int j = 0; j < D; j++) {
+              const double v = r.a(j) * sddi + r.b(j) * sd2;
+              if (v + kTiny < r.lo(j) || v - kTiny > r.hi(j)) { ok = false; break; }
+            }
+            if (ok) {
+              if (sddi > smax) smax = sddi;
+              if (sddi < smin) smin = sddi;
+            }
+          }
         }
       }
     }

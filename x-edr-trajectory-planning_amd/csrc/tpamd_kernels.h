@@ -24,7 +24,11 @@ struct Workspace {
   uint32_t *err_bits;
   double *lim;  // [B][2][C] lower then upper (joint mode)
   // per (path, sample)
-  double *q12;  // [B][N][2D] (joint mode)
+  // joint mode: one record of R = 2D+2 doubles per sample,
+  //   [q'_0, q''_0, ..., q'_{D-1}, q''_{D-1}, sd2_max (final), type bits]
+  // so that the sweep streams exactly one contiguous record per step. The first 2D
+  // entries are written by k_sample_lp_joint, the last two by k_boundary_final.
+  double *q12;
   double *m0, *z0, *X0, *Y0, *Xz, *Yz;  // pass-1 boundary, [B][N]
   uint8_t *at0;                          // sd2_max_at_sdd0
   uint8_t *fix_flag;
@@ -32,16 +36,25 @@ struct Workspace {
   double *m, *X, *Y;  // final boundary
   uint8_t *type;
   double *sd2;
+  long long *diag;  // [B][16] cycle counters; filled only by -DTPAMD_DIAG builds
 };
 
 struct JointSource {
-  const double *q12;  // [B][N][2D]
+  const double *q12;  // [B][N][2D+2] records
   const double *lim;  // [B][2][2D]
   int D;
   __device__ __forceinline__ int rows() const { return 2 * D; }
+  static constexpr bool kJoint = true;
+  __device__ __forceinline__ int stride() const { return 2 * D + 2; }
+  // final boundary value and classification into the sample's record
+  __device__ __forceinline__ void put_record(int b, int N, int idx, double m, uint8_t type) const {
+    double *rec = const_cast<double *>(q12) + ((size_t)b * N + idx) * (2 * D + 2) + 2 * D;
+    rec[0] = m;
+    rec[1] = __longlong_as_double((long long)type);
+  }
   __device__ __forceinline__ JointRowsAt at(int b, int N, int idx) const {
     JointRowsAt r;
-    r.q12 = q12 + ((size_t)b * N + idx) * (2 * D);
+    r.q12 = q12 + ((size_t)b * N + idx) * (2 * D + 2);
     r.lim_lo = lim + (size_t)b * 4 * D;
     r.lim_hi = r.lim_lo + 2 * D;
     r.D = D;
@@ -53,6 +66,8 @@ struct GenericSource {
   const double *A, *B, *LO, *HI;  // [B][N][C]
   int C;
   __device__ __forceinline__ int rows() const { return C; }
+  static constexpr bool kJoint = false;
+  __device__ __forceinline__ void put_record(int, int, int, double, uint8_t) const {}
   __device__ __forceinline__ GlobalRowsAt at(int b, int N, int idx) const {
     const size_t o = ((size_t)b * N + idx) * C;
     GlobalRowsAt r;
@@ -127,16 +142,18 @@ __global__ void k_setup_rows(int B, int N, const double *s_start, const double *
 }
 
 // ------------------------------------------------- pass 1, common tail per sample
-template <int WORDS, class R>
+template <int WORDS, bool JOINT, class R>
 __device__ __forceinline__ void boundary_point(const R &r, int C, size_t o, Workspace ws) {
   double sd2max, sddmax, sd2zero;
   lp_find_max_sd2<WORDS>(r, C, &sd2max, &sddmax, &sd2zero);
   double x0, y0, xz, yz;
-  find_sdd_both(r, C, sd2max, &x0, &y0);
+  if (JOINT) find_sdd_both_joint(r, C / 2, sd2max, &x0, &y0);
+  else find_sdd_both(r, C, sd2max, &x0, &y0);
   if (sd2zero == sd2max) {
     xz = x0; yz = y0;
   } else {
-    find_sdd_both(r, C, sd2zero, &xz, &yz);
+    if (JOINT) find_sdd_both_joint(r, C / 2, sd2zero, &xz, &yz);
+    else find_sdd_both(r, C, sd2zero, &xz, &yz);
   }
   ws.m0[o] = sd2max;
   ws.z0[o] = sd2zero;
@@ -149,7 +166,7 @@ __device__ __forceinline__ void boundary_point(const R &r, int C, size_t o, Work
 
 // ---------------------------------------------------- K1 (joint): sample + LP
 // grid = (ceil(N/TPB), B), block = TPB. Dynamic LDS:
-//   knots[P+3] | control points [P][D] | lim_lo[2D] | lim_hi[2D] | A[2D][TPB] | B[2D][TPB]
+//   knots[P+3] | control points [P][D] | lim_lo[2D] | lim_hi[2D] | q'[D][TPB] | q''[D][TPB]
 // SamplePath: timeable_path_joint_spline.cc:294-318; EvalCurveAndDerivatives:
 // splines/bspline.h:540-568; ConstraintSetup: timeable_path_joint_spline.cc:320-343;
 // CalculateBoundary pass 1: time_optimal_path_timing.cc:1366-1377.
@@ -166,8 +183,8 @@ __global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
   double *s_cp = s_knots + K;
   double *s_lo = s_cp + P * D;
   double *s_hi = s_lo + C;
-  double *s_A = s_hi + C;
-  double *s_B = s_A + (size_t)C * TPB;
+  double *s_Q1 = s_hi + C;
+  double *s_Q2 = s_Q1 + (size_t)D * TPB;
   for (int k = tid; k < K; k += TPB) s_knots[k] = knots_g[(size_t)b * K + k];
   for (int k = tid; k < P * D; k += TPB) s_cp[k] = cps_g[(size_t)b * P * D + k];
   for (int k = tid; k < 2 * C; k += TPB) s_lo[k] = ws.lim[(size_t)b * 2 * C + k];
@@ -180,8 +197,8 @@ __global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
   const double delta = ws.delta[b];
   const double k0 = s_knots[0], kend = s_knots[K - 1];
   const double parameter = path_start + i * delta;
-  double *q12 = ws.q12 + o * C;
-  double *A = s_A + tid, *Bv = s_B + tid;
+  double *q12 = ws.q12 + o * (C + 2);
+  double *Q1 = s_Q1 + tid, *Q2 = s_Q2 + tid;
   if (parameter < kend + delta) {
     double u = parameter;
     if (u < k0) u = k0;
@@ -196,28 +213,22 @@ __global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
       v1 += ders[1][0] * p0[d]; v1 += ders[1][1] * p1[d]; v1 += ders[1][2] * p2[d];
       v2 += ders[2][0] * p0[d]; v2 += ders[2][1] * p1[d]; v2 += ders[2][2] * p2[d];
       if (q_out) q_out[o * D + d] = v0;
-      q12[d] = v1;
-      q12[D + d] = v2;
-      A[d * TPB] = v1;
-      Bv[d * TPB] = v2;
-      A[(D + d) * TPB] = 0.0;
-      Bv[(D + d) * TPB] = v1 * v1;
+      *reinterpret_cast<double2 *>(q12 + 2 * d) = make_double2(v1, v2);
+      Q1[d * TPB] = v1;
+      Q2[d * TPB] = v2;
     }
   } else {
     const double *pl = s_cp + (size_t)(P - 1) * D;
     for (int d = 0; d < D; d++) {
       if (q_out) q_out[o * D + d] = pl[d];
-      q12[d] = 0.0;
-      q12[D + d] = 0.0;
-      A[d * TPB] = 0.0;
-      Bv[d * TPB] = 0.0;
-      A[(D + d) * TPB] = 0.0;
-      Bv[(D + d) * TPB] = 0.0;
+      *reinterpret_cast<double2 *>(q12 + 2 * d) = make_double2(0.0, 0.0);
+      Q1[d * TPB] = 0.0;
+      Q2[d * TPB] = 0.0;
     }
   }
-  LdsRows r;
-  r.A = A; r.B = Bv; r.LO = s_lo; r.HI = s_hi; r.stride = TPB; r.lim_stride = 1;
-  boundary_point<WORDS>(r, C, o, ws);
+  LdsRowsJoint r;
+  r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
+  boundary_point<WORDS, true>(r, C, o, ws);
 }
 
 // ------------------------------------------------ K1 (rows): validation + LP
@@ -258,7 +269,7 @@ __global__ void k_lp_rows(int N, int C, const double *Ag, const double *Bg, cons
   if (maxw <= 0) bits |= kErrInfeasible;
   if (lge) bits |= kErrLowerGeUpper;
   if (bits) atomicOr(&ws.err_bits[b], bits);
-  boundary_point<WORDS>(r, C, o, ws);
+  boundary_point<WORDS, false>(r, C, o, ws);
 }
 
 // Stand-alone batched LP (tpamd_find_max_sd2_host): one thread per LP.
@@ -370,7 +381,8 @@ __global__ void k_boundary_final(int N, Source src, Workspace ws) {
   } else if (f_self) {
     m = ws.fix_val[pb + j];
     const auto r = src.at(b, N, j);
-    find_sdd_both(r, src.rows(), m, &X, &Y);
+    if (Source::kJoint) find_sdd_both_joint(r, src.rows() / 2, m, &X, &Y);
+    else find_sdd_both(r, src.rows(), m, &X, &Y);
   } else if (iso_at(at, N, j + 1)) {
     m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
   } else if (iso_at(at, N, j - 1)) {
@@ -392,7 +404,11 @@ __global__ void k_boundary_final(int N, Source src, Workspace ws) {
     else if (sd2p > sd2p_max) type = kBndSource;
     if ((sd2p <= sd2p_max) && (sd2p >= sd2p_min)) type = kBndTrajectory;
   }
+  // bit 3 is not part of the reference's classification: it caches the comparison
+  // NextCriticalPoint makes against sd2_max_for_sdd0[0] (.cc:710) for the sweep kernel.
+  if (m == ws.z0[pb]) type |= kBndEqualsZ00;
   ws.type[pb + j] = type;
+  src.put_record(b, N, j, m, type);
 }
 
 // ------------------------------------------------------------- K2: the sweep
@@ -583,71 +599,23 @@ struct Sweep {
   }
 };
 
-// Dynamic LDS: sd2[N] | sdd[N] | dt[64]
+// Common tail of the sweep kernels (time_optimal_path_timing.cc:398-477): NaN
+// check, sdd fill-in at extremal intersections, start acceleration, sqrt,
+// last_extremal_index_, time integration, outputs. `status` is the outcome of the
+// switching-point loop (0, 7 or 10). sd2 is an LDS array [N]; sdd is either an LDS
+// array (copy_sdd: written out at the end) or the output row itself; dtl is an LDS
+// scratch of 64 doubles.
 template <class Source>
-__global__ void __launch_bounds__(64)
-k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s_out,
-        double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
-        int32_t *status_out) {
-  extern __shared__ double lds[];
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+__device__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N, int lane,
+                           int status, double *sd2, double *sdd, double *dtl, bool copy_sdd,
+                           double *t_out, double *s_out, double *sd_out, double *sdd_out,
+                           int32_t *lei_out, double *dtmax_out, int32_t *status_out) {
   const size_t pb = (size_t)b * N;
-  const uint32_t bits = ws.err_bits[b];
-  if (bits) {
-    if (lane == 0) {
-      status_out[b] = status_from_bits(bits);
-      if (lei_out) lei_out[b] = 0;
-      if (dtmax_out) dtmax_out[b] = -1.0;
-    }
-    return;
-  }
+  const double ds = ws.ds[b];
   Sweep<Source> S;
   S.src = src; S.b = b; S.N = N; S.C = src.rows(); S.lane = lane;
-  S.ds = ws.ds[b];
-  S.sd2 = lds; S.sdd = lds + N;
+  S.ds = ds; S.sd2 = sd2; S.sdd = sdd;
   S.m = ws.m + pb; S.type = ws.type + pb;
-  double *sd2 = S.sd2, *sdd = S.sdd;
-  const double ds = S.ds;
-  const double sd_start = ws.sd_start[b];
-
-  for (int i = lane; i < N; i += 64) { sd2[i] = qnan(); sdd[i] = qnan(); }
-  __syncthreads();
-  if (lane == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
-  __syncthreads();
-
-  int status = 0;
-  int iforw_lo = 0, iback_hi = N - 1, iback_lo, iforw_hi, icrit, icrit_lo, icrit_hi;
-  iback_lo = S.add_backward(iback_hi);
-  iforw_hi = S.add_forward(iforw_lo);
-  icrit_hi = iback_lo;
-  if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
-    S.put_sd2(icrit_hi, qnan());
-    icrit_hi++;
-    iback_lo++;
-  }
-  icrit_lo = iforw_hi;
-  const double z00 = ws.z0[pb];
-  for (int loop = 0; loop < max_loops; loop++) {
-    if (iforw_hi >= icrit_hi) break;
-    icrit = S.next_critical_point(icrit_lo, icrit_hi, z00);
-    if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
-    if (icrit > 0 && icrit < N - 1) S.put_sd2(icrit, S.m[icrit]);
-    if (icrit < 1) { status = 10; break; }
-    if (S.m[icrit - 1] <= S.m[icrit]) {
-      iback_hi = icrit - 1;
-      S.put_sd2(icrit - 1, S.m[icrit - 1]);
-    } else {
-      iback_hi = icrit;
-    }
-    iback_lo = S.add_backward(iback_hi);
-    iforw_lo = icrit;
-    iforw_hi = S.add_forward(iforw_lo);
-    if (iback_lo > icrit_lo) { status = 7; break; }
-    icrit_lo = iforw_hi;
-  }
-  __syncthreads();
-
   // NaN check and sdd fill-in (.cc:398-411); every index is independent.
   if (status == 0) {
     bool has_nan = false;
@@ -706,7 +674,6 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
   // sd = sqrt(sd2) (.cc:420), time integration (.cc:447-467). dt of 64 samples is
   // computed in parallel; the running sum keeps the reference's left-to-right
   // order (each lane re-adds the tile's increments in sequence).
-  double *dtl = lds + 2 * (size_t)N;
   const double t0 = ws.t_start[b];
   const double s0 = ws.s_start[b], s1 = ws.s_end[b];
   double tprev = t0;  // time_[base-1]
@@ -753,7 +720,8 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
   }
   dtmax = wave_max_f64(dtmax);
   __syncthreads();
-  for (int idx = lane; idx < N; idx += 64) sdd_out[pb + idx] = sdd[idx];
+  if (copy_sdd)
+    for (int idx = lane; idx < N; idx += 64) sdd_out[pb + idx] = sdd[idx];
   if (lane == 0) {
     status_out[b] = 0;
     if (lei_out) lei_out[b] = lei;
@@ -761,28 +729,96 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
   }
 }
 
+// Dynamic LDS: sd2[N] | sdd[N] | dt[64]
+template <class Source>
+__global__ void __launch_bounds__(64)
+k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s_out,
+        double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
+        int32_t *status_out) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const size_t pb = (size_t)b * N;
+  const uint32_t bits = ws.err_bits[b];
+  if (bits) {
+    if (lane == 0) {
+      status_out[b] = status_from_bits(bits);
+      if (lei_out) lei_out[b] = 0;
+      if (dtmax_out) dtmax_out[b] = -1.0;
+    }
+    return;
+  }
+  Sweep<Source> S;
+  S.src = src; S.b = b; S.N = N; S.C = src.rows(); S.lane = lane;
+  S.ds = ws.ds[b];
+  S.sd2 = lds; S.sdd = lds + N;
+  S.m = ws.m + pb; S.type = ws.type + pb;
+  double *sd2 = S.sd2, *sdd = S.sdd;
+  const double sd_start = ws.sd_start[b];
+
+  for (int i = lane; i < N; i += 64) { sd2[i] = qnan(); sdd[i] = qnan(); }
+  __syncthreads();
+  if (lane == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
+  __syncthreads();
+
+  int status = 0;
+  int iforw_lo = 0, iback_hi = N - 1, iback_lo, iforw_hi, icrit, icrit_lo, icrit_hi;
+  iback_lo = S.add_backward(iback_hi);
+  iforw_hi = S.add_forward(iforw_lo);
+  icrit_hi = iback_lo;
+  if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
+    S.put_sd2(icrit_hi, qnan());
+    icrit_hi++;
+    iback_lo++;
+  }
+  icrit_lo = iforw_hi;
+  const double z00 = ws.z0[pb];
+  for (int loop = 0; loop < max_loops; loop++) {
+    if (iforw_hi >= icrit_hi) break;
+    icrit = S.next_critical_point(icrit_lo, icrit_hi, z00);
+    if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
+    if (icrit > 0 && icrit < N - 1) S.put_sd2(icrit, S.m[icrit]);
+    if (icrit < 1) { status = 10; break; }
+    if (S.m[icrit - 1] <= S.m[icrit]) {
+      iback_hi = icrit - 1;
+      S.put_sd2(icrit - 1, S.m[icrit - 1]);
+    } else {
+      iback_hi = icrit;
+    }
+    iback_lo = S.add_backward(iback_hi);
+    iforw_lo = icrit;
+    iforw_hi = S.add_forward(iforw_lo);
+    if (iback_lo > icrit_lo) { status = 7; break; }
+    icrit_lo = iforw_hi;
+  }
+  __syncthreads();
+  sweep_tail(src, ws, b, N, lane, status, lds, lds + N, lds + 2 * (size_t)N, /*copy_sdd=*/true,
+             t_out, s_out, sd_out, sdd_out, lei_out, dtmax_out, status_out);
+}
+
 // -------------------------------------------------------------- K3: epilogue
-// path_timing_trajectory.cc:458-472. One thread per (path, sample).
-__global__ void k_epilogue(int B, int N, int D, const double *q12, const double *sd,
+// path_timing_trajectory.cc:458-472. One thread per (path, sample, joint): the reads of
+// the (q', q'') pairs and the writes of qd/qdd are contiguous across a wave.
+__global__ void k_epilogue(int B, int N, int D, const double *rec, const double *sd,
                            const double *sdd, const double *amax, const int32_t *status,
                            double *qd, double *qdd) {
-  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= (size_t)B * N) return;
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * N * D;
+  if (e >= total) return;
+  const size_t o = e / D;           // (path, sample)
+  const int d = (int)(e - o * D);
   const int b = (int)(o / N);
   if (status[b] != 0) return;
   const double v = sd[o], a = sdd[o];
   const double v2 = v * v;
-  const double *p = q12 + o * 2 * D;
-  for (int d = 0; d < D; d++) {
-    const double q1 = p[d], q2 = p[D + d];
-    const double am = amax[(size_t)b * D + d];
-    if (qd) qd[o * D + d] = q1 * v;
-    if (qdd) {
-      double acc = q1 * a + q2 * v2;
-      if (acc < -am) acc = -am;
-      if (acc > am) acc = am;
-      qdd[o * D + d] = acc;
-    }
+  const double2 pr = *reinterpret_cast<const double2 *>(rec + o * (2 * D + 2) + 2 * d);
+  const double am = amax[(size_t)b * D + d];
+  if (qd) qd[e] = pr.x * v;
+  if (qdd) {
+    double acc = pr.x * a + pr.y * v2;
+    if (acc < -am) acc = -am;
+    if (acc > am) acc = am;
+    qdd[e] = acc;
   }
 }
 

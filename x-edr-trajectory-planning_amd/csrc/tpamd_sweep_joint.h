@@ -1,0 +1,527 @@
+// tpamd_sweep_joint.h -- the sweep kernel specialised for joint-space paths
+// (C = 2D rows with the structure of timeable_path_joint_spline.cc:320-343).
+//
+// One 64-lane wave per path, as the generic k_sweep, but:
+//  * D is a template parameter: every row loop is unrolled.
+//  * Memory: each sample has one contiguous record of R = 2D+2 doubles
+//    [q'_d, q''_d pairs | final sd2_max | type bits] (written by k_sample_lp_joint and
+//    k_boundary_final). The sweep touches records strictly sequentially, so they are
+//    staged through LDS in tiles of 32 samples: the tile after the current one (in
+//    sweep direction) is fetched into registers by all 64 lanes with coalesced 16-byte
+//    loads while the current tile is being consumed, and dropped into the 2-slot LDS
+//    ring when the sweep reaches it. Per step the wave then reads its record from LDS
+//    (broadcast reads), one step ahead of use. No global-memory latency is left on the
+//    sequential chain except one tile fill at the start of an extremal that begins
+//    outside the two resident tiles.
+//  * sd2_ lives in LDS; sdd_ is written straight to the output array (it is never
+//    read back inside the extremal loops); the type bytes are copied to LDS once for the
+//    switching-point search.
+//  * FindSddMax/FindSddMin exploit the row structure. Rows D..2D-1 have A = 0, so
+//    (time_optimal_path_timing.cc:650) they generate no candidates, and for a
+//    finite candidate sdd their validity test v = 0*sdd + q'^2*sd2 does not depend
+//    on the candidate: it is evaluated once per step by D otherwise idle lanes.
+//    Non-finite candidates can never be selected in the reference either: an
+//    infinite one violates its own row (|A| >= kTiny there), a NaN one fails the
+//    "sddi > sdd" comparison. The 2D candidates of rows 0..D-1 sit one per lane,
+//    each lane validates its candidate against the D acceleration rows, and a
+//    DPP butterfly over 16-lane rows keeps the extreme valid candidate.
+//  * Solver scalars are re-uniformised with readfirstlane after cross-lane steps so
+//    that the control flow is scalar.
+// The arithmetic (operands, order, no contraction) is the generic kernel's and
+// the reference's; results are bit-identical.
+#pragma once
+
+#include "tpamd_kernels.h"
+
+namespace tpamd {
+
+__device__ __forceinline__ double uniform_f64(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Extreme value over each 16-lane DPP row (butterfly: xor 1, xor 2, half-row
+// mirror, row mirror). Inputs must not be NaN.
+template <bool MAX>
+__device__ __forceinline__ double row16_extreme(double v) {
+  double o;
+  o = dpp_f64<0xB1>(v);  v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // quad_perm [1,0,3,2]
+  o = dpp_f64<0x4E>(v);  v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // quad_perm [2,3,0,1]
+  o = dpp_f64<0x141>(v); v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // row_half_mirror
+  o = dpp_f64<0x140>(v); v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // row_mirror
+  return v;
+}
+
+// Diagnostic build only (-DTPAMD_DIAG): per-path cycle counters written to ws.diag;
+// the product build contains none of this.
+#ifdef TPAMD_DIAG
+#define TPAMD_T0(var) const long long var = __builtin_readcyclecounter()
+#define TPAMD_ACC(slot, var) diag[slot] += __builtin_readcyclecounter() - (var)
+#define TPAMD_CNT(slot) diag[slot] += 1
+#else
+#define TPAMD_T0(var)
+#define TPAMD_ACC(slot, var)
+#define TPAMD_CNT(slot)
+#endif
+
+constexpr int kTileSamples = 32;
+
+// Lane layout of one FindSddMax/FindSddMin step (D joints, 2D candidates):
+//   lane = c * PARTS + p,  c = candidate (row r = c >> 1, bound = c & 1), p = part.
+//   The PARTS lanes of a candidate all compute the same candidate value and each
+//   validates it against its own share of the D acceleration rows (rows p, p+PARTS,
+//   ...); a candidate is admissible iff all its parts agree. PARTS = 4 for D <= 7
+//   (56 lanes for D = 7), 2 for D <= 16, so that 2D * PARTS <= 64.
+//   Lanes [0, D) additionally check one velocity row each.
+template <int D>
+struct JointLayout {
+  static constexpr int PARTS = (D <= 7) ? 4 : ((D <= 16) ? 2 : 1);
+  static constexpr int RPL = (D + PARTS - 1) / PARTS;        // rows validated per lane
+  static constexpr int kCandLanes = 2 * D * PARTS;
+  static constexpr int kRows16 = (kCandLanes + 15) / 16;     // 16-lane DPP rows in use
+  static_assert(kCandLanes <= 64, "candidate lanes must fit one wave");
+};
+
+template <bool MAX>
+__device__ __forceinline__ double ext2(double a, double b) {
+  return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b);
+}
+
+template <int D>
+struct JointSweep {
+  typedef JointLayout<D> L;
+  static constexpr int R = 2 * D + 2;                       // doubles per record
+  static constexpr int kChunks = kTileSamples * R / 2;      // 16-byte chunks per tile
+  static constexpr int kChunksPerLane = (kChunks + 63) / 64;
+#ifdef TPAMD_DIAG
+  long long diag[16];
+#endif
+  int N, lane;
+  double ds, two_ds;
+  double *sd2;            // LDS [N]
+  double *tiles;          // LDS [2][kTileSamples][R]
+  const uint8_t *typel;   // LDS [N] copy of the type bytes
+  double *sdd_g;          // global: sdd output row of this path
+  const double *rec;      // global: records of this path [N][R]
+  int tag0, tag1;         // tile index resident in ring slot 0 / 1 (-1: none)
+  int pf_tag;             // tile index held in the prefetch registers (-1: none)
+  double2 pf[kChunksPerLane];
+  // per-lane constants (roles are folded into data so that the hot loop has no role
+  // branches): idle lanes carry lim = NaN (their candidate is NaN, hence rejected) and
+  // vel_hi = +inf (their velocity check never fails).
+  double lim;             // the bound defining this lane's candidate
+  double chk_hi[L::RPL];  // upper bounds of the acceleration rows this lane validates
+  double vel_hi;          // upper bound of the velocity row this lane checks
+  int own_off;            // offsets (in double2 units) of the pairs this lane reads
+  int chk_off[L::RPL];
+  int vel_off;
+  double row_lo, row_hi;  // AreDerivativesValid: lane j < 2D owns row j
+
+  struct Rows {
+    double2 own;            // (q', q'') of the candidate's row
+    double2 chk[L::RPL];    // pairs of the rows this lane validates
+    double2 vel;            // pair of the velocity row this lane checks
+  };
+
+  // ---- tile ring -----------------------------------------------------------
+  // Loads always cover a full tile: a partial last tile reads at most 31 records past
+  // the path's end, which is still inside the engine workspace (never used).
+  __device__ __forceinline__ void issue_tile_loads(int t) {
+    const double2 *src = reinterpret_cast<const double2 *>(rec + (size_t)t * kTileSamples * R);
+#pragma unroll
+    for (int k = 0; k < kChunksPerLane; k++) {
+      const int c = lane + 64 * k;
+      if (kChunks % 64 == 0 || k < kChunksPerLane - 1 || c < kChunks) pf[k] = src[c];
+    }
+    pf_tag = t;
+  }
+  __device__ __forceinline__ void store_tile(int slot) {
+    double2 *dst = reinterpret_cast<double2 *>(tiles + (size_t)slot * kTileSamples * R);
+#pragma unroll
+    for (int k = 0; k < kChunksPerLane; k++) {
+      const int c = lane + 64 * k;
+      if (kChunks % 64 == 0 || k < kChunksPerLane - 1 || c < kChunks) dst[c] = pf[k];
+    }
+    __syncthreads();
+  }
+  // Make tile t resident; dir tells which neighbour tile to prefetch afterwards.
+  __device__ __forceinline__ void fill_tile(int t, int dir) {
+    TPAMD_CNT(12);
+    if (pf_tag != t) { TPAMD_CNT(13); issue_tile_loads(t); }
+    __syncthreads();                 // earlier readers of this slot are done
+    store_tile(t & 1);               // waits for the loads, writes LDS
+    if (t & 1) tag1 = t; else tag0 = t;
+    const int tn = t + dir;
+    pf_tag = -1;
+    if (tn >= 0 && tn * kTileSamples < N) issue_tile_loads(tn);
+  }
+  __device__ __forceinline__ void ensure_tile(int idx, int dir) {
+    const int t = idx / kTileSamples;
+    const int tag = (t & 1) ? tag1 : tag0;
+    if (tag != t) fill_tile(t, dir);
+  }
+  __device__ __forceinline__ const double2 *record(int idx) const {
+    // slot = (idx / 32) & 1, position = idx % 32  ==  idx & 63 in a 64-record ring
+    return reinterpret_cast<const double2 *>(tiles) + (size_t)(idx & (2 * kTileSamples - 1)) * (R / 2);
+  }
+  __device__ __forceinline__ void load_rows(int idx, Rows &r) const {
+    const double2 *p = record(idx);
+    r.own = p[own_off];
+#pragma unroll
+    for (int k = 0; k < L::RPL; k++) r.chk[k] = p[chk_off[k]];
+    r.vel = p[vel_off];
+  }
+  __device__ __forceinline__ void load_mt(int idx, double &m, int &t) const {
+    const double2 v = record(idx)[D];
+    m = v.x;
+    t = __double2loint(v.y);
+  }
+
+  __device__ __forceinline__ void put_sd2(int i, double v) {
+    if (lane == 0) sd2[i] = v;
+    __builtin_amdgcn_wave_barrier();
+  }
+  __device__ __forceinline__ void put_sdd(int i, double v) {
+    if (lane == 0) sdd_g[i] = v;
+  }
+
+  // FindSddMax (MAX) / FindSddMin, time_optimal_path_timing.cc:638-695.
+  template <bool MAX>
+  __device__ __forceinline__ double find_sdd(const Rows &r, double s2) const {
+    constexpr double kSentinel = MAX ? -DBL_MAX : DBL_MAX;
+    // velocity row of this lane: v = q'^2 * sd2 against [0, (vmax*safety)^2]
+    const double vv = (r.vel.x * r.vel.x) * s2;
+    const bool vel_bad = (vv + kTiny < 0.0) | (vv - kTiny > vel_hi);
+    // candidate of this lane's group
+    const double sddi = (lim - r.own.y * s2) / r.own.x;
+    bool bad = (fabs(r.own.x) < kTiny) | (sddi != sddi);
+#pragma unroll
+    for (int k = 0; k < L::RPL; k++) {
+      const double v = r.chk[k].x * sddi + r.chk[k].y * s2;
+      bad = bad | (v + kTiny < -chk_hi[k]) | (v - kTiny > chk_hi[k]);
+    }
+    double best = bad ? kSentinel : sddi;
+    // all parts of a candidate must agree: the group keeps the sentinel if any part set it
+    if (L::PARTS >= 2) best = ext2<!MAX>(best, dpp_f64<0xB1>(best));   // xor 1
+    if (L::PARTS >= 4) best = ext2<!MAX>(best, dpp_f64<0x4E>(best));   // xor 2
+    // extreme over the candidates of each 16-lane row
+    if (L::PARTS < 2) best = ext2<MAX>(best, dpp_f64<0xB1>(best));
+    if (L::PARTS < 4) best = ext2<MAX>(best, dpp_f64<0x4E>(best));
+    best = ext2<MAX>(best, dpp_f64<0x141>(best));                      // row_half_mirror
+    best = ext2<MAX>(best, dpp_f64<0x140>(best));                      // row_mirror
+    double res = readlane_f64(best, 0);
+#pragma unroll
+    for (int k = 1; k < L::kRows16; k++) res = ext2<MAX>(res, readlane_f64(best, 16 * k));
+    if (res == kSentinel) res = 0;
+    if (__ballot(vel_bad) != 0ull) res = 0;
+    return res;
+  }
+
+  // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
+  __device__ bool derivs_valid(int idx, double sddv, double s2) const {
+    bool bad = false;
+    if (lane < 2 * D) {
+      const int d = (lane < D) ? lane : lane - D;
+      const double2 pr = *reinterpret_cast<const double2 *>(rec + (size_t)idx * R + 2 * d);
+      const double A = (lane < D) ? pr.x : 0.0;
+      const double Bc = (lane < D) ? pr.y : pr.x * pr.x;
+      const double v = A * sddv + Bc * s2;
+      bad = (v + kTiny < row_lo) || (v - kTiny > row_hi);
+    }
+    return __ballot(bad) == 0ull;
+  }
+
+  // ComputeSddAtIntersection, .cc:722-751: symmetric, forward, backward difference of
+  // sd2 in that order; the first admissible one wins, else 0.
+  __device__ __forceinline__ void sdd_at_intersection(int index) {
+    const double s2 = sd2[index];
+    const bool has_next = index < N - 1, has_prev = index > 0;
+    double res = 0.0;
+    bool done = false;
+    if (has_next && has_prev) {
+      const double c = 0.25 / ds * (sd2[index + 1] - sd2[index - 1]);
+      if (derivs_valid(index, c, s2)) { res = c; done = true; }
+    }
+    if (!done && has_next) {
+      const double c = 0.5 / ds * (sd2[index + 1] - s2);
+      if (derivs_valid(index, c, s2)) { res = c; done = true; }
+    }
+    if (!done && has_prev) {
+      const double c = 0.5 / ds * (s2 - sd2[index - 1]);
+      if (derivs_valid(index, c, s2)) { res = c; done = true; }
+    }
+    put_sdd(index, res);
+  }
+
+  // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952)
+  // otherwise. "n" = the neighbour the extremal moves to (idx+1 or idx-1).
+  template <bool FWD>
+  __device__ int add_extremal(int idx_start) {
+    constexpr int dir = FWD ? 1 : -1;
+    int idx = idx_start;
+    if (FWD ? !(idx < N - 2) : !(idx > 1)) return FWD ? N - 1 : 0;
+    Rows cur_rows, nxt_rows;
+    ensure_tile(idx, dir);
+    ensure_tile(idx + dir, dir);
+    load_rows(idx, cur_rows);
+    double cur = uniform_f64(sd2[idx]);
+    double m_i, m_n;
+    int t_i, t_n;
+    load_mt(idx, m_i, t_i);
+    load_mt(idx + dir, m_n, t_n);
+    m_i = uniform_f64(m_i); m_n = uniform_f64(m_n);
+    t_i = uniform_i32(t_i); t_n = uniform_i32(t_n);
+    for (;;) {
+      const int nidx = idx + dir;
+      const bool more = FWD ? (nidx < N - 2) : (nidx > 1);
+      // stage the next step's data (1 <= nidx <= N-2, 0 <= nidx+dir <= N-1); a new tile
+      // can only be entered at a tile edge
+      if (((nidx + dir) & (kTileSamples - 1)) == (FWD ? 0 : kTileSamples - 1))
+        ensure_tile(nidx + dir, dir);
+      load_rows(nidx, nxt_rows);
+      double m_nn;
+      int t_nn;
+      load_mt(nidx + dir, m_nn, t_nn);
+      const double nxt = uniform_f64(sd2[nidx]);
+      const bool on_boundary = is_tiny(cur - m_i);
+      double sd2tmp, sddtmp;
+      if (on_boundary && (t_i & kBndTrajectory) && (t_n & kBndTrajectory)) {
+        TPAMD_CNT(FWD ? 8 : 9);
+        sd2tmp = m_n;
+        sddtmp = FWD ? 0.5 * (sd2tmp - cur) / ds : 0.5 * (cur - sd2tmp) / ds;
+      } else {
+        TPAMD_CNT(FWD ? 10 : 11);
+        sddtmp = uniform_f64(find_sdd<FWD>(cur_rows, cur));
+        sd2tmp = FWD ? cur + two_ds * sddtmp : cur - two_ds * sddtmp;
+      }
+      if (!isnan(nxt) && (nxt < sd2tmp)) {
+        sdd_at_intersection(idx);
+        return FWD ? N - 1 : 0;
+      }
+      if (sd2tmp > m_n) {
+        const double sdd_bound = FWD ? 0.5 * (m_n - cur) / ds : 0.5 * (cur - m_n) / ds;
+        const bool deriv_invalid = !derivs_valid(idx, sdd_bound, FWD ? m_i : cur);
+        const bool type_invalid = t_n & (FWD ? kBndSink : kBndSource);
+        const bool stop = FWD ? (type_invalid || deriv_invalid)
+                              : ((type_invalid || deriv_invalid) && !(idx_start != (N - 1)));
+        if (stop) return idx;
+        sd2tmp = m_n;
+        sddtmp = sdd_bound;
+      }
+      if (sd2tmp < 0) {
+        sd2tmp = 0.0;
+        if (FWD) {
+          if (idx <= 1) sddtmp = 0.0; else sddtmp = -sd2[idx - 1] / ds;
+        } else {
+          if (idx < N - 1) sddtmp = sd2[idx + 1] / ds; else sddtmp = 0.0;
+        }
+      }
+      put_sd2(nidx, sd2tmp);
+      put_sdd(idx, sddtmp);
+      if (!more) return FWD ? N - 1 : 0;
+      idx = nidx;
+      cur = sd2tmp;
+      m_i = m_n;
+      t_i = t_n;
+      m_n = uniform_f64(m_nn);
+      t_n = uniform_i32(t_nn);
+      cur_rows = nxt_rows;
+    }
+  }
+
+  // NextCriticalPoint, .cc:697-720, as two wave-parallel scans over the LDS copies of
+  // type and sd2:
+  //  1. first idx in (lo, hi] classified source or trajectory -> c0 (none: -1);
+  //  2. first idx >= c0 whose sd2 is already set -> e (none: -1); the answer is the
+  //     last idx in (c0, e] with sd2_max[idx] == sd2_max_for_sdd0[0] (sic, index 0,
+  //     .cc:710; cached as bit kBndEqualsZ00 of the type byte), else c0.
+  __device__ int next_critical_point(int idx_lo, int idx_hi) const {
+    int c0 = -1;
+    for (int base = idx_lo + 1; base <= idx_hi && c0 < 0; base += 64) {
+      const int idx = base + lane;
+      const bool hit = (idx <= idx_hi) && (typel[idx] & (kBndSource | kBndTrajectory));
+      const unsigned long long mask = __ballot(hit);
+      if (mask) c0 = base + __ffsll((long long)mask) - 1;
+    }
+    if (c0 < 0) return -1;
+    int crit = c0;
+    for (int base = c0; base <= idx_hi; base += 64) {
+      const int idx = base + lane;
+      const bool in = idx <= idx_hi;
+      const bool set = in && !isnan(sd2[idx]);
+      const bool isol = in && (idx > c0) && (typel[idx] & kBndEqualsZ00);
+      const unsigned long long mset = __ballot(set);
+      unsigned long long miso = __ballot(isol);
+      if (mset) {
+        const int e = __ffsll((long long)mset) - 1;
+        if (e < 63) miso &= (2ull << e) - 1ull;
+        if (miso) crit = base + 63 - __clzll((long long)miso);
+        return crit;
+      }
+      if (miso) crit = base + 63 - __clzll((long long)miso);
+    }
+    return -1;
+  }
+};
+
+// Dynamic LDS (bytes): sd2[N]*8 | dt[64]*8 | tiles 2*32*R*8 | type copy N (padded to 16)
+template <int D>
+__host__ __device__ inline size_t sweep_joint_lds_bytes(int N) {
+  return (size_t)N * 8 + 64 * 8 + 2 * (size_t)kTileSamples * (2 * D + 2) * 8 +
+         (((size_t)N + 15) / 16) * 16;
+}
+
+template <int D>
+__global__ void __launch_bounds__(64)
+k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
+              double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
+              int32_t *status_out) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const size_t pb = (size_t)b * N;
+  const uint32_t bits = ws.err_bits[b];
+  if (bits) {
+    if (lane == 0) {
+      status_out[b] = status_from_bits(bits);
+      if (lei_out) lei_out[b] = 0;
+      if (dtmax_out) dtmax_out[b] = -1.0;
+    }
+    return;
+  }
+  typedef JointSweep<D> JS;
+  JS S;
+  S.N = N; S.lane = lane;
+  S.ds = ws.ds[b];
+  S.two_ds = 2.0 * S.ds;
+  S.sd2 = lds;
+  double *dtl = lds + N;
+  S.tiles = dtl + 64;
+  uint8_t *typel = reinterpret_cast<uint8_t *>(S.tiles + 2 * kTileSamples * JS::R);
+  S.typel = typel;
+  S.sdd_g = sdd_out + pb;
+  S.rec = src.q12 + pb * JS::R;
+  S.tag0 = -1; S.tag1 = -1; S.pf_tag = -1;
+  const double *lim_lo = src.lim + (size_t)b * 4 * D, *lim_hi = lim_lo + 2 * D;
+  {
+    typedef JointLayout<D> L;
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+    const bool is_cand = lane < L::kCandLanes;
+    const int c = is_cand ? lane / L::PARTS : 0;     // candidate
+    const int p = lane % L::PARTS;                   // part
+    const int r = c >> 1;                            // its row
+    S.own_off = r;
+    S.lim = is_cand ? ((c & 1) ? lim_hi[r] : lim_lo[r]) : qnan();
+#pragma unroll
+    for (int k = 0; k < L::RPL; k++) {
+      int j = p + k * L::PARTS;
+      if (j >= D) j = p;                             // short share: re-check an own row
+      S.chk_off[k] = j;
+      S.chk_hi[k] = lim_hi[j];
+    }
+    const bool is_vel = lane < D;
+    S.vel_off = is_vel ? lane : 0;
+    S.vel_hi = is_vel ? lim_hi[D + lane] : kInf;
+  }
+  S.row_lo = (lane < 2 * D) ? lim_lo[lane] : 0.0;
+  S.row_hi = (lane < 2 * D) ? lim_hi[lane] : 0.0;
+
+  double *sd2 = S.sd2;
+  const double sd_start = ws.sd_start[b];
+  const uint8_t *type_g = ws.type + pb;
+  for (int i = lane; i < N; i += 64) {
+    sd2[i] = qnan();
+    S.sdd_g[i] = qnan();
+    typel[i] = type_g[i];
+  }
+  __syncthreads();
+  if (lane == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
+  __syncthreads();
+
+  int status = 0;
+  int iforw_lo = 0, iback_hi = N - 1, iback_lo, iforw_hi, icrit, icrit_lo, icrit_hi;
+#ifdef TPAMD_DIAG
+  long long(&diag)[16] = S.diag;
+  for (int k = 0; k < 16; k++) diag[k] = 0;
+#endif
+  TPAMD_T0(t_all);
+  {
+    TPAMD_T0(t0);
+    iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi));
+    TPAMD_ACC(1, t0);
+  }
+  {
+    TPAMD_T0(t0);
+    iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo));
+    TPAMD_ACC(0, t0);
+  }
+  icrit_hi = iback_lo;
+  if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
+    S.put_sd2(icrit_hi, qnan());
+    icrit_hi++;
+    iback_lo++;
+  }
+  icrit_lo = iforw_hi;
+  const double *m_g = ws.m + pb;
+  for (int loop = 0; loop < max_loops; loop++) {
+    if (iforw_hi >= icrit_hi) break;
+    {
+      TPAMD_T0(t0);
+      icrit = uniform_i32(S.next_critical_point(icrit_lo, icrit_hi));
+      TPAMD_ACC(2, t0);
+    }
+    if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
+    if (icrit > 0 && icrit < N - 1) S.put_sd2(icrit, m_g[icrit]);
+    if (icrit < 1) { status = 10; break; }
+    if (m_g[icrit - 1] <= m_g[icrit]) {
+      iback_hi = icrit - 1;
+      S.put_sd2(icrit - 1, m_g[icrit - 1]);
+    } else {
+      iback_hi = icrit;
+    }
+    {
+      TPAMD_T0(t0);
+      iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi));
+      TPAMD_ACC(1, t0);
+    }
+    iforw_lo = icrit;
+    {
+      TPAMD_T0(t0);
+      iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo));
+      TPAMD_ACC(0, t0);
+    }
+    if (iback_lo > icrit_lo) { status = 7; break; }
+    icrit_lo = iforw_hi;
+  }
+  TPAMD_ACC(5, t_all);
+  // sdd_ was written with plain global stores by lane 0; make it visible to all lanes
+  __threadfence_block();
+  __syncthreads();
+  {
+    TPAMD_T0(t0);
+    sweep_tail(src, ws, b, N, lane, status, sd2, S.sdd_g, dtl, /*copy_sdd=*/false, t_out, s_out,
+               sd_out, sdd_out, lei_out, dtmax_out, status_out);
+    TPAMD_ACC(3, t0);
+  }
+#ifdef TPAMD_DIAG
+  if (lane == 0 && ws.diag)
+    for (int k = 0; k < 16; k++) ws.diag[(size_t)b * 16 + k] = S.diag[k];
+#endif
+}
+
+}  // namespace tpamd

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_CSRC, "libtpamd.so")
-_SOURCES = ["tpamd_capi.hip", "tpamd_kernels.h", "tpamd_device.h"]
+_SOURCES = ["tpamd_capi.hip", "tpamd_kernels.h", "tpamd_device.h", "tpamd_sweep_joint.h"]
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "tpamd.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
@@ -33,13 +33,17 @@ class TpamdError(RuntimeError):
     pass
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, extra_flags=(), output=None):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    global _SO
+    if output is not None:
+        _SO = output
     deps = [os.path.join(_CSRC, s) for s in _SOURCES] + [_HEADER]
     stale = force or not os.path.exists(_SO) or any(
         os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps)
     if stale:
-        cmd = ["hipcc"] + HIPCC_FLAGS + ["-o", _SO, os.path.join(_CSRC, "tpamd_capi.hip")]
+        cmd = (["hipcc"] + HIPCC_FLAGS + list(extra_flags) +
+               ["-o", _SO, os.path.join(_CSRC, "tpamd_capi.hip")])
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=_CSRC)
@@ -92,7 +96,7 @@ ABI_SYMBOLS = [
     "tpamd_engine_reserve", "tpamd_engine_workspace_bytes", "tpamd_time_joint_paths_device",
     "tpamd_time_joint_paths_host", "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
-    "tpamd_debug_copy_boundary", "tpamd_profile_reset", "tpamd_profile_enable",
+    "tpamd_debug_copy_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
     "tpamd_profile_mean_ms", "tpamd_profile_kernel_name", "tpamd_profile_num_kernels",
 ]
 
@@ -138,6 +142,8 @@ def load_library():
     L.tpamd_resample_uniform_device.argtypes = [vp, C.POINTER(_ResampleArgs), vp]
     L.tpamd_debug_copy_boundary.restype = i
     L.tpamd_debug_copy_boundary.argtypes = [vp, i, i] + [vp] * 6
+    L.tpamd_debug_copy_diag.restype = i
+    L.tpamd_debug_copy_diag.argtypes = [vp, i, vp]
     L.tpamd_profile_reset.argtypes = [vp]
     L.tpamd_profile_enable.argtypes = [vp, i]
     L.tpamd_profile_mean_ms.restype = C.c_double
@@ -282,6 +288,11 @@ class Engine:
             _ptr(arr["sd2_zero"]), _ptr(arr["type"]), _ptr(arr["sd2"])),
             "tpamd_debug_copy_boundary")
         return arr
+
+    def debug_diag(self, B):
+        out = np.zeros((B, 16), dtype=np.int64)
+        _check(self._lib.tpamd_debug_copy_diag(self._h, B, _ptr(out)), "tpamd_debug_copy_diag")
+        return out
 
     # ---------------------------------------------------------------- timing
     def profile_enable(self, on=True):
