@@ -113,6 +113,7 @@ typedef struct tpamd_path_outputs {
   int32_t *last_extremal_index; /* [B] GetLastExtremalIndex(); may be NULL */
   double *max_time_increment;   /* [B] GetMaxTimeIncrement(); may be NULL */
   int32_t *status;              /* [B] TPAMD_PATH_* */
+  double *sd2;                  /* [B][N] squared path velocity sd2_ (sd = sqrt(sd2)); may be NULL */
 } tpamd_path_outputs;
 
 int tpamd_time_joint_paths_device(tpamd_engine *engine, const tpamd_joint_batch *batch,
@@ -121,6 +122,15 @@ int tpamd_time_joint_paths_device(tpamd_engine *engine, const tpamd_joint_batch 
 int tpamd_time_joint_paths_host(tpamd_engine *engine, const tpamd_joint_batch *batch,
                                 const tpamd_joint_inputs *in,
                                 const tpamd_path_outputs *out);
+
+/* Stand-alone batched TimeableJointSplinePath::SamplePath
+ * (timeable_path_joint_spline.cc:294-318): q, q' = dq/ds, q'' = d2q/ds2 at
+ * path_start + i*delta, i < N, as [B][N][D] host arrays (GetPathPositionAt,
+ * GetFirstPathDerivativeAt, GetSecondPathDerivativeAt). */
+int tpamd_sample_joint_paths_host(tpamd_engine *engine, int num_paths, int num_dofs,
+                                  int num_samples, int num_points, const double *knots,
+                                  const double *control_points, const double *path_start,
+                                  const double *delta, double *q, double *q1, double *q2);
 
 /* ------------------------------------------------------------------------
  * Form (ii): explicit constraint rows  lower <= A*sdd + B*sd^2 <= upper.
@@ -196,6 +206,8 @@ typedef struct tpamd_resample_args {
 
 int tpamd_resample_uniform_device(tpamd_engine *engine, const tpamd_resample_args *args,
                                   void *hip_stream);
+/* Same with HOST pointers in args (copies in, runs, copies out, synchronises). */
+int tpamd_resample_uniform_host(tpamd_engine *engine, const tpamd_resample_args *args);
 
 /* ------------------------------------------------------------------------
  * Debug/inspection: copy the boundary curve of the LAST solve to host arrays

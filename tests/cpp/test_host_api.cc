@@ -1,0 +1,256 @@
+// GPU test of the host mirror of the reference's C++ API (run by tests/test_gpu_host_api.py).
+// The oracle is linked here only as the checker.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "../../oracle/tp_oracle.h"
+#include "../../x-edr-trajectory-planning_amd/host/batch_path_timing.h"
+#include "../../x-edr-trajectory-planning_amd/host/path_timing_trajectory.h"
+#include "../../x-edr-trajectory-planning_amd/host/time_optimal_path_timing.h"
+#include "../../x-edr-trajectory-planning_amd/host/timeable_path_joint_spline.h"
+
+using namespace trajectory_planning;
+using tpamd::compat::FromUnixSeconds;
+using tpamd::compat::Milliseconds;
+using tpamd::compat::Seconds;
+
+static int g_fail = 0;
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); g_fail++; } \
+  } while (0)
+
+using Constraint = TimeOptimalPathProfile::Constraint;
+constexpr double kTiny = 2.220446049250313e-16 * 1e5;
+
+// circle scenario of the reference's solver test (time_optimal_path_timing_test.cc:125-158)
+static std::vector<Constraint> CircleRows(int n, double s0, double s1, double R, double vmax, double amax) {
+  std::vector<Constraint> c(n);
+  const double ds = (s1 - s0) / (n - 1);
+  for (int i = 0; i < n; i++) {
+    const double s = i * ds + s0;
+    c[i].resize(4);
+    c[i].a_coefficient(0) = -R * std::sin(s); c[i].a_coefficient(1) = R * std::cos(s);
+    c[i].a_coefficient(2) = 0; c[i].a_coefficient(3) = 0;
+    c[i].b_coefficient(0) = -R * std::cos(s); c[i].b_coefficient(1) = -R * std::sin(s);
+    c[i].b_coefficient(2) = std::pow(R * std::sin(s), 2); c[i].b_coefficient(3) = std::pow(R * std::cos(s), 2);
+    c[i].upper(0) = amax; c[i].upper(1) = amax; c[i].upper(2) = vmax * vmax; c[i].upper(3) = vmax * vmax;
+    c[i].lower(0) = -amax; c[i].lower(1) = -amax; c[i].lower(2) = 0; c[i].lower(3) = 0;
+  }
+  return c;
+}
+
+static void TestProfileAgainstOracle() {
+  for (int n : {50, 51}) {
+    for (double sd0 : {0.0, 0.1}) {
+      auto rows = CircleRows(n, 0.0, M_PI, 2.0, 1.2, 1.0);
+      TimeOptimalPathProfile opt;
+      CHECK(opt.InitSolver(n, 4));
+      CHECK(opt.SetupProblem(rows, 0.0, M_PI, sd0, 0.0, 0.0));
+      CHECK(opt.OptimizePathParameter());
+      CHECK(opt.SolutionSatisfiesConstraints().ok());
+      double s, sd, sdd;
+      CHECK(opt.GetPathParameterAndDerivatives(0.0, &s, &sd, &sdd));
+      CHECK(sd == sd0);   // time_optimal_path_timing_test.cc:538-541
+      // oracle on the same rows
+      std::vector<double> A(n * 4), B(n * 4), lo(n * 4), hi(n * 4);
+      for (int i = 0; i < n; i++)
+        for (int c = 0; c < 4; c++) {
+          A[i * 4 + c] = rows[i].a_coefficient(c); B[i * 4 + c] = rows[i].b_coefficient(c);
+          lo[i * 4 + c] = rows[i].lower(c); hi[i * 4 + c] = rows[i].upper(c);
+        }
+      tpo_profile *p = tpo_profile_create(n, 4);
+      CHECK(tpo_profile_setup(p, A.data(), B.data(), lo.data(), hi.data(), 0.0, M_PI, sd0, 0.0, 0.0) == 0);
+      CHECK(tpo_profile_optimize(p) == 0);
+      for (int i = 0; i < n; i++) {
+        CHECK(opt.GetTimeSamples()[i] == tpo_profile_time(p)[i]);
+        CHECK(opt.GetPathParameter()[i] == tpo_profile_s(p)[i]);
+        CHECK(opt.GetPathVelocity()[i] == tpo_profile_sd(p)[i]);
+        CHECK(opt.GetPathAcceleration()[i] == tpo_profile_sdd(p)[i]);
+      }
+      CHECK(opt.GetLastExtremalIndex() == tpo_profile_last_extremal_index(p));
+      CHECK(opt.GetMaxTimeIncrement() == tpo_profile_max_time_increment(p));
+      const double T = opt.GetEndTime();
+      for (int k = -2; k <= 102; k++) {
+        const double t = T * k / 100.0;
+        double os, osd, osdd;
+        CHECK(opt.GetPathParameterAndDerivatives(t, &s, &sd, &sdd));
+        CHECK(tpo_profile_query(p, t, &os, &osd, &osdd) == 1);
+        CHECK(s == os && sd == osd && sdd == osdd);
+        CHECK(opt.GetPreviousIndex(t) == tpo_profile_previous_index(p, t));
+      }
+      tpo_profile_destroy(p);
+    }
+  }
+  // failure modes keep the reference's bool convention
+  auto rows = CircleRows(20, 0.0, M_PI, 2.0, 1.2, 1.0);
+  TimeOptimalPathProfile opt;
+  CHECK(!opt.OptimizePathParameter());                 // not set up
+  CHECK(opt.InitSolver(20, 4));
+  CHECK(!opt.SetupProblem(rows, M_PI, M_PI, 0, 0, 0));  // s_start >= s_end
+  CHECK(!opt.SetupProblem(rows, 0, M_PI, -1, 0, 0));    // sd_start < 0
+  rows[3].upper(0) = rows[3].lower(0);
+  CHECK(!opt.SetupProblem(rows, 0, M_PI, 0, 0, 0));     // lower >= upper
+  // one LP through the class API
+  Constraint c;
+  c.resize(2);
+  c.a_coefficient(0) = 1; c.b_coefficient(0) = 0; c.lower(0) = -1; c.upper(0) = 1;
+  c.a_coefficient(1) = 0; c.b_coefficient(1) = 1; c.lower(1) = 0; c.upper(1) = 4;
+  double sd2max, sddmax, sd2zero;
+  opt.FindMaxSd2Simplex(c, &sd2max, &sddmax, &sd2zero);
+  CHECK(sd2max == 4.0 && sd2zero == 4.0);
+}
+
+static std::shared_ptr<TimeableJointSplinePath> MakePath(int N, const std::vector<VectorXd> &wps,
+                                                         double vmax, double amax, double *delta_out) {
+  const size_t D = wps[0].size();
+  // first fit with a provisional option set to learn the spline length, as a user would
+  // pick delta_parameter from the path length
+  auto probe = std::make_shared<TimeableJointSplinePath>(
+      JointPathOptions().set_num_dofs(D).set_num_path_samples(N));
+  probe->SetWaypoints({wps.data(), wps.size()});
+  const double delta = probe->knots().back() / (N - 1);
+  auto path = std::make_shared<TimeableJointSplinePath>(
+      JointPathOptions().set_num_dofs(D).set_num_path_samples(N).set_delta_parameter(delta));
+  std::vector<double> v(D, vmax), a(D, amax);
+  CHECK(path->SetMaxJointVelocity({v.data(), v.size()}).ok());
+  CHECK(path->SetMaxJointAcceleration({a.data(), a.size()}).ok());
+  CHECK(path->SetWaypoints({wps.data(), wps.size()}).ok());
+  if (delta_out) *delta_out = delta;
+  return path;
+}
+
+static void TestJointPathAndPlanner() {
+  // path_timing_trajectory_test.cc:112-173: waypoints (1,2,3), (-1,-2,-3), (1,2,3)
+  const std::vector<VectorXd> wps = {VectorXd{1, 2, 3}, VectorXd{-1, -2, -3}, VectorXd{1, 2, 3}};
+  const int N = 1000;
+  double delta = 0;
+  auto path = MakePath(N, wps, 1.0, 2.0, &delta);
+  CHECK(path->GetState() == TimeablePath::State::kNewPath);
+  // fit and sampling against the oracle
+  std::vector<double> w(9), cps(7 * 3), knots(10);
+  for (int i = 0; i < 3; i++) for (int d = 0; d < 3; d++) w[i * 3 + d] = wps[i][d];
+  CHECK(tpo_joint_fit_spline(w.data(), 3, 3, 0.2, cps.data(), knots.data()) == 7);
+  CHECK(path->num_control_points() == 7);
+  for (int k = 0; k < 10; k++) CHECK(path->knots()[k] == knots[k]);
+  for (int k = 0; k < 21; k++) CHECK(path->packed_control_points()[k] == cps[k]);
+  CHECK(path->SamplePath(0.0).ok());
+  CHECK(path->ConstraintSetup().ok());
+  std::vector<double> q(N * 3), q1(N * 3), q2(N * 3);
+  CHECK(tpo_joint_sample_path(knots.data(), 10, cps.data(), 7, 3, 0.0, delta, N, q.data(), q1.data(), q2.data()) == 0);
+  for (int i = 0; i < N; i++)
+    for (int d = 0; d < 3; d++) {
+      CHECK(path->GetPathPositionAt(i)[d] == q[i * 3 + d]);
+      CHECK(path->GetFirstPathDerivativeAt(i)[d] == q1[i * 3 + d]);
+      CHECK(path->GetSecondPathDerivativeAt(i)[d] == q2[i * 3 + d]);
+    }
+  CHECK(path->GetConstraints()[10].a_coefficient(1) == q1[10 * 3 + 1]);
+  CHECK(path->GetConstraints()[10].b_coefficient(3 + 1) == q1[10 * 3 + 1] * q1[10 * 3 + 1]);
+  CHECK(path->GetConstraints()[10].upper(3) == (1.0 * 0.8) * (1.0 * 0.8));
+  CHECK(path->GetParameterEnd() == N * delta);   // sic, quirk Q7
+
+  for (auto method : {PathTimingTrajectoryOptions::TimeSamplingMethod::kUniformlyInTime,
+                      PathTimingTrajectoryOptions::TimeSamplingMethod::kSkipSamplesCloserThanTimeStep}) {
+    auto opts = PathTimingTrajectoryOptions().SetNumDofs(3).SetNumPathSamples(N).SetTimeStep(Milliseconds(4))
+                    .SetTimeSamplingMethod(method);
+    auto run = [&](double t0, std::vector<double> *times, std::vector<VectorXd> *pos) {
+      auto p = MakePath(N, wps, 1.0, 2.0, nullptr);
+      PathTimingTrajectory planner(opts);
+      CHECK(planner.SetPath(p).ok());
+      const auto st = planner.Plan(FromUnixSeconds(t0), Seconds(1000.0));
+      if (!st.ok()) std::printf("plan: %s\n", st.ToString().c_str());
+      CHECK(st.ok());
+      CHECK(planner.IsTrajectoryAtEnd());
+      CHECK(planner.GetNumTimeSamples() > 100);
+      // end position = last waypoint, end velocity = 0 (path_timing_trajectory_test.cc:167-172)
+      for (int d = 0; d < 3; d++) {
+        CHECK(std::fabs(planner.GetPositions().back()[d] - wps.back()[d]) < 1e-10);
+        CHECK(planner.GetVelocities().back()[d] == 0.0);
+      }
+      for (const auto &v : planner.GetVelocities()) CHECK(v.maxAbs() <= 1.0 * 0.8 + 1e-9);
+      for (const auto &a : planner.GetAccelerations()) CHECK(a.maxAbs() <= 2.0 + 1e-12);
+      *times = planner.GetTime();
+      *pos = planner.GetPositions();
+      // Reset + replan reproduces the trajectory exactly (:533-545)
+      planner.Reset();
+      CHECK(p->GetState() == TimeablePath::State::kNoPath);
+      CHECK(p->SetWaypoints({wps.data(), wps.size()}).ok());
+      CHECK(planner.Plan(FromUnixSeconds(t0), Seconds(1000.0)).ok());
+      CHECK(planner.GetTime() == *times);
+      CHECK(planner.GetPositions().size() == pos->size());
+      for (size_t i = 0; i < pos->size(); i++) CHECK(planner.GetPositions()[i] == (*pos)[i]);
+    };
+    std::vector<double> t_a, t_b;
+    std::vector<VectorXd> p_a, p_b;
+    run(0.0, &t_a, &p_a);
+    run(100.0, &t_b, &p_b);
+    // invariance to the start time within 1e-10 (:254-296)
+    CHECK(t_a.size() == t_b.size());
+    for (size_t i = 0; i < std::min(t_a.size(), t_b.size()); i++) {
+      CHECK(std::fabs((t_b[i] - 100.0) - t_a[i]) < 1e-9);
+      for (int d = 0; d < 3; d++) CHECK(std::fabs(p_a[i][d] - p_b[i][d]) < 1e-10);
+    }
+    if (method == PathTimingTrajectoryOptions::TimeSamplingMethod::kUniformlyInTime)
+      for (size_t i = 1; i < t_a.size(); i++) CHECK(std::fabs(t_a[i] - t_a[i - 1] - 0.004) < 1e-12);
+  }
+  // mismatched path is rejected (path_timing_trajectory.cc:850-861)
+  PathTimingTrajectory planner(PathTimingTrajectoryOptions().SetNumDofs(4).SetNumPathSamples(N).SetTimeStep(Milliseconds(4)));
+  CHECK(!planner.SetPath(path).ok());
+  CHECK(!planner.Plan(FromUnixSeconds(0), Seconds(1)).ok());
+}
+
+static void TestBatch() {
+  const int B = 24, D = 7, N = 500, W = 6;
+  std::vector<std::shared_ptr<TimeableJointSplinePath>> paths;
+  unsigned long long seed = 12345;
+  auto rnd = [&]() { seed = seed * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(seed >> 11) / 9007199254740992.0; };
+  std::vector<double> deltas(B);
+  for (int b = 0; b < B; b++) {
+    std::vector<VectorXd> wps;
+    for (int i = 0; i < W; i++) {
+      VectorXd v(D);
+      for (int d = 0; d < D; d++) v[d] = 4.0 * rnd() - 2.0;
+      wps.push_back(v);
+    }
+    paths.push_back(MakePath(N, wps, 1.0 + rnd(), 2.0 + 2.0 * rnd(), &deltas[b]));
+  }
+  BatchPathTiming batch;
+  CHECK(batch.SetPaths(paths).ok());
+  BatchTimingResult r;
+  CHECK(batch.ComputeTimingProfiles(1.5, &r).ok());
+  const int P = 3 * W - 2;
+  for (int b = 0; b < B; b++) {
+    CHECK(r.status[b] == 0);
+    std::vector<double> t(N), s(N), sd(N), sdd(N), q(N * D), qd(N * D), qdd(N * D);
+    int lei = 0;
+    const int rc = tpo_time_joint_path(paths[b]->knots().data(), P + 3, paths[b]->packed_control_points().data(),
+                                       P, D, paths[b]->GetMaxJointVelocity().data(),
+                                       paths[b]->GetMaxJointAcceleration().data(), 0.8, 0.0, deltas[b], N,
+                                       0.0, 0.0, 1.5, nullptr, t.data(), s.data(), sd.data(), sdd.data(),
+                                       q.data(), qd.data(), qdd.data(), &lei);
+    CHECK(rc == 0);
+    CHECK(lei == r.last_extremal_index[b]);
+    for (int i = 0; i < N; i++) {
+      CHECK(r.time[(size_t)b * N + i] == t[i]);
+      CHECK(r.sd[(size_t)b * N + i] == sd[i]);
+      CHECK(r.sdd[(size_t)b * N + i] == sdd[i]);
+    }
+    for (int i = 0; i < N * D; i++) {
+      CHECK(r.q[(size_t)b * N * D + i] == q[i]);
+      CHECK(r.qd[(size_t)b * N * D + i] == qd[i]);
+      CHECK(r.qdd[(size_t)b * N * D + i] == qdd[i]);
+    }
+  }
+}
+
+int main() {
+  TestProfileAgainstOracle();
+  TestJointPathAndPlanner();
+  TestBatch();
+  if (g_fail == 0) std::printf("ALL OK\n");
+  else std::printf("%d CHECKS FAILED\n", g_fail);
+  return g_fail == 0 ? 0 : 1;
+}

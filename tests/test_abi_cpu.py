@@ -23,7 +23,7 @@ def test_header_symbols_are_all_exported(eng):
     hdr = open(os.path.join(ROOT, "include", "tpamd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(tpamd_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 20
+    assert len(declared) >= 22
     assert declared == set(eng.ABI_SYMBOLS)
     lib = eng.load_library()
     for name in sorted(declared):
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header(eng):
     # sizes implied by the C declarations (LP64): 6 int32 + double; 9 / 10 pointers; ...
     assert ctypes.sizeof(eng._JointBatch) == 32
     assert ctypes.sizeof(eng._JointInputs) == 72
-    assert ctypes.sizeof(eng._PathOutputs) == 80
+    assert ctypes.sizeof(eng._PathOutputs) == 88
     assert ctypes.sizeof(eng._RowsBatch) == 16
     assert ctypes.sizeof(eng._RowsInputs) == 72
     assert ctypes.sizeof(eng._ResampleArgs) == 16 + 9 * 8 + 8 + 8 + 8 * 8

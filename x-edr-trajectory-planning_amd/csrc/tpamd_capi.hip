@@ -208,6 +208,7 @@ void launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, cons
 template <class Source>
 int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int max_loops,
                            const Source &src, const tpamd_path_outputs *out) {
+  e->ws.sd2_out = out->sd2;
   const Workspace &ws = e->ws;
   const dim3 grid_s((N + 255) / 256, B);
   {
@@ -401,6 +402,7 @@ int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
     double *d_qdd = out->qdd ? s.take<double>(B * N * D) : nullptr;
     int32_t *d_lei = s.take<int32_t>(B), *d_st = s.take<int32_t>(B);
     double *d_dtm = s.take<double>(B);
+    double *d_sd2 = out->sd2 ? s.take<double>(B * N) : nullptr;
     if (!pass) {
       int rc = ensure_stage(e, s.off);
       if (rc) return rc;
@@ -420,9 +422,10 @@ int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
       HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
     HIPCHK(hipMemcpyAsync(d_t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
     tpamd_joint_inputs din{d_knots, d_cp, d_vmax, d_amax, d_ps, d_dl, d_sd0, d_sdd0, d_t0};
-    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, d_q, d_qd, d_qdd, d_lei, d_dtm, d_st};
+    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, d_q, d_qd, d_qdd, d_lei, d_dtm, d_st, d_sd2};
     int rc = tpamd_time_joint_paths_device(e, bt, &din, &dout, st);
     if (rc) return rc;
+    if (out->sd2) HIPCHK(hipMemcpyAsync(out->sd2, d_sd2, B * N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->time, d_t, B * N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->s, d_s, B * N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->sd, d_sd, B * N * 8, hipMemcpyDeviceToHost, st));
@@ -435,6 +438,44 @@ int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
     if (out->max_time_increment)
       HIPCHK(hipMemcpyAsync(out->max_time_increment, d_dtm, B * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->status, d_st, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
+int tpamd_sample_joint_paths_host(tpamd_engine *e, int num_paths, int num_dofs, int num_samples,
+                                  int num_points, const double *knots,
+                                  const double *control_points, const double *path_start,
+                                  const double *delta, double *q, double *q1, double *q2) {
+  if (!e || !knots || !control_points || !path_start || !delta || !q || !q1 || !q2)
+    return TPAMD_E_INVALID_ARGUMENT;
+  if (num_paths <= 0) return num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (num_dofs < 1 || num_samples < 1 || num_points < 3) return TPAMD_E_UNSUPPORTED;
+  const size_t B = num_paths, D = num_dofs, N = num_samples, P = num_points;
+  HIPCHK(hipSetDevice(e->device));
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_knots = s.take<double>(B * (P + 3)), *d_cp = s.take<double>(B * P * D);
+    double *d_ps = s.take<double>(B), *d_dl = s.take<double>(B);
+    double *d_q = s.take<double>(B * N * D), *d_q1 = s.take<double>(B * N * D),
+           *d_q2 = s.take<double>(B * N * D);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(d_knots, knots, B * (P + 3) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cp, control_points, B * P * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ps, path_start, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_dl, delta, B * 8, hipMemcpyHostToDevice, st));
+    const size_t lds = (P + 3 + P * D) * 8;
+    hipLaunchKernelGGL(k_sample_only, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256),
+                       lds, st, (int)N, (int)D, (int)P, d_knots, d_cp, d_ps, d_dl, d_q, d_q1, d_q2);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(q, d_q, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(q1, d_q1, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(q2, d_q2, B * N * D * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
   }
   return 0;
@@ -456,6 +497,7 @@ int tpamd_optimize_rows_host(tpamd_engine *e, const tpamd_rows_batch *bt,
     double *d_sd = s.take<double>(B * N), *d_sdd = s.take<double>(B * N);
     int32_t *d_lei = s.take<int32_t>(B), *d_st = s.take<int32_t>(B);
     double *d_dtm = s.take<double>(B);
+    double *d_sd2 = out->sd2 ? s.take<double>(B * N) : nullptr;
     if (!pass) {
       int rc = ensure_stage(e, s.off);
       if (rc) return rc;
@@ -475,9 +517,11 @@ int tpamd_optimize_rows_host(tpamd_engine *e, const tpamd_rows_batch *bt,
       HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
     HIPCHK(hipMemcpyAsync(d_t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
     tpamd_rows_inputs din{d_a, d_b, d_lo, d_hi, d_s0, d_s1, d_sd0, d_sdd0, d_t0};
-    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, nullptr, nullptr, nullptr, d_lei, d_dtm, d_st};
+    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, nullptr, nullptr, nullptr, d_lei, d_dtm, d_st,
+                            d_sd2};
     int rc = tpamd_optimize_rows_device(e, bt, &din, &dout, st);
     if (rc) return rc;
+    if (out->sd2) HIPCHK(hipMemcpyAsync(out->sd2, d_sd2, B * N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->time, d_t, B * N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->s, d_s, B * N * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(out->sd, d_sd, B * N * 8, hipMemcpyDeviceToHost, st));
@@ -568,6 +612,60 @@ int tpamd_resample_uniform_device(tpamd_engine *e, const tpamd_resample_args *a,
   hipLaunchKernelGGL(k_resample, dim3((a->max_out + 255) / 256, a->num_paths), dim3(256), 0,
                      (hipStream_t)hip_stream, p);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tpamd_resample_uniform_host(tpamd_engine *e, const tpamd_resample_args *a) {
+  if (!e || !a) return TPAMD_E_INVALID_ARGUMENT;
+  if (a->num_paths <= 0) return a->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = a->num_paths, N = a->num_samples, D = a->num_dofs, M = a->max_out;
+  HIPCHK(hipSetDevice(e->device));
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_t = s.take<double>(B * N), *d_s = s.take<double>(B * N), *d_sd = s.take<double>(B * N),
+           *d_sdd = s.take<double>(B * N);
+    double *d_q = s.take<double>(B * N * D), *d_qd = s.take<double>(B * N * D),
+           *d_qdd = s.take<double>(B * N * D);
+    double *d_am = s.take<double>(B * D), *d_st = s.take<double>(B);
+    int32_t *d_status = a->status ? s.take<int32_t>(B) : nullptr;
+    double *o_t = s.take<double>(B * M), *o_s = s.take<double>(B * M), *o_sd = s.take<double>(B * M),
+           *o_sdd = s.take<double>(B * M);
+    double *o_q = s.take<double>(B * M * D), *o_qd = s.take<double>(B * M * D),
+           *o_qdd = s.take<double>(B * M * D);
+    int32_t *o_cnt = s.take<int32_t>(B);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(d_t, a->time, B * N * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_s, a->s, B * N * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sd, a->sd, B * N * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sdd, a->sdd, B * N * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_q, a->q, B * N * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_qd, a->qd, B * N * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_qdd, a->qdd, B * N * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_am, a->max_acceleration, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_st, a->start_sec, B * 8, hipMemcpyHostToDevice, st));
+    if (d_status) HIPCHK(hipMemcpyAsync(d_status, a->status, B * 4, hipMemcpyHostToDevice, st));
+    tpamd_resample_args da = *a;
+    da.time = d_t; da.s = d_s; da.sd = d_sd; da.sdd = d_sdd; da.q = d_q; da.qd = d_qd; da.qdd = d_qdd;
+    da.max_acceleration = d_am; da.start_sec = d_st; da.status = d_status;
+    da.out_time = o_t; da.out_s = o_s; da.out_sd = o_sd; da.out_sdd = o_sdd;
+    da.out_q = o_q; da.out_qd = o_qd; da.out_qdd = o_qdd; da.count = o_cnt;
+    int rc = tpamd_resample_uniform_device(e, &da, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(a->out_time, o_t, B * M * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->out_s, o_s, B * M * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->out_sd, o_sd, B * M * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->out_sdd, o_sdd, B * M * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->out_q, o_q, B * M * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->out_qd, o_qd, B * M * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->out_qdd, o_qdd, B * M * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->count, o_cnt, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
   return 0;
 }
 

@@ -37,6 +37,7 @@ struct Workspace {
   uint8_t *type;
   double *sd2;
   long long *diag;  // [B][16] cycle counters; filled only by -DTPAMD_DIAG builds
+  double *sd2_out;  // optional caller copy of sd2 ([B][N]); may be null
 };
 
 struct JointSource {
@@ -229,6 +230,45 @@ __global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
   LdsRowsJoint r;
   r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
   boundary_point<WORDS, true>(r, C, o, ws);
+}
+
+// Sampling only (TimeableJointSplinePath::SamplePath as a stand-alone call,
+// timeable_path_joint_spline.cc:294-318): q, q', q'' as [B][N][D] arrays.
+// grid = (ceil(N/TPB), B); dynamic LDS: knots[P+3] | control points [P][D].
+__global__ void k_sample_only(int N, int D, int P, const double *knots_g, const double *cps_g,
+                              const double *path_start, const double *delta_g, double *q,
+                              double *q1, double *q2) {
+  extern __shared__ double lds[];
+  const int TPB = blockDim.x, tid = threadIdx.x, b = blockIdx.y, K = P + 3;
+  double *s_knots = lds, *s_cp = lds + K;
+  for (int k = tid; k < K; k += TPB) s_knots[k] = knots_g[(size_t)b * K + k];
+  for (int k = tid; k < P * D; k += TPB) s_cp[k] = cps_g[(size_t)b * P * D + k];
+  __syncthreads();
+  const int i = blockIdx.x * TPB + tid;
+  if (i >= N) return;
+  const size_t o = ((size_t)b * N + i) * D;
+  const double delta = delta_g[b];
+  const double k0 = s_knots[0], kend = s_knots[K - 1];
+  const double parameter = path_start[b] + i * delta;
+  if (parameter < kend + delta) {
+    double u = parameter;
+    if (u < k0) u = k0;
+    if (kend < u) u = kend;
+    const int span = knot_span_deg2(s_knots, K, u);
+    double ders[3][3];
+    basis_ders_deg2(s_knots, span, u, ders);
+    const double *p0 = s_cp + (size_t)(span - 2) * D, *p1 = p0 + D, *p2 = p1 + D;
+    for (int d = 0; d < D; d++) {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      v0 += ders[0][0] * p0[d]; v0 += ders[0][1] * p1[d]; v0 += ders[0][2] * p2[d];
+      v1 += ders[1][0] * p0[d]; v1 += ders[1][1] * p1[d]; v1 += ders[1][2] * p2[d];
+      v2 += ders[2][0] * p0[d]; v2 += ders[2][1] * p1[d]; v2 += ders[2][2] * p2[d];
+      q[o + d] = v0; q1[o + d] = v1; q2[o + d] = v2;
+    }
+  } else {
+    const double *pl = s_cp + (size_t)(P - 1) * D;
+    for (int d = 0; d < D; d++) { q[o + d] = pl[d]; q1[o + d] = 0.0; q2[o + d] = 0.0; }
+  }
 }
 
 // ------------------------------------------------ K1 (rows): validation + LP
@@ -709,6 +749,7 @@ __device__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N,
       sd_out[pb + idx] = sdv;
       s_out[pb + idx] = (idx == N - 1) ? s1 : ds * idx + s0;
       ws.sd2[pb + idx] = sd2[idx];
+      if (ws.sd2_out) ws.sd2_out[pb + idx] = sd2[idx];
       if (dt > dtmax) dtmax = dt;
     }
     // zero acceleration across stationary pairs (.cc:463-465)

@@ -65,7 +65,7 @@ class _JointInputs(C.Structure):
 class _PathOutputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
-        "max_time_increment", "status")]
+        "max_time_increment", "status", "sd2")]
 
 
 class _RowsBatch(C.Structure):
@@ -94,8 +94,10 @@ _LIB = None
 ABI_SYMBOLS = [
     "tpamd_engine_create", "tpamd_engine_destroy", "tpamd_version", "tpamd_error_string",
     "tpamd_engine_reserve", "tpamd_engine_workspace_bytes", "tpamd_time_joint_paths_device",
-    "tpamd_time_joint_paths_host", "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
+    "tpamd_time_joint_paths_host", "tpamd_sample_joint_paths_host",
+    "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
+    "tpamd_resample_uniform_host",
     "tpamd_debug_copy_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
     "tpamd_profile_mean_ms", "tpamd_profile_kernel_name", "tpamd_profile_num_kernels",
 ]
@@ -128,6 +130,8 @@ def load_library():
     L.tpamd_time_joint_paths_host.restype = i
     L.tpamd_time_joint_paths_host.argtypes = [vp, C.POINTER(_JointBatch),
                                               C.POINTER(_JointInputs), C.POINTER(_PathOutputs)]
+    L.tpamd_sample_joint_paths_host.restype = i
+    L.tpamd_sample_joint_paths_host.argtypes = [vp, i, i, i, i] + [vp] * 7
     L.tpamd_optimize_rows_device.restype = i
     L.tpamd_optimize_rows_device.argtypes = [vp, C.POINTER(_RowsBatch), C.POINTER(_RowsInputs),
                                              C.POINTER(_PathOutputs), vp]
@@ -140,6 +144,8 @@ def load_library():
     L.tpamd_query_device.argtypes = [vp, i, i, i] + [vp] * 9 + [vp]
     L.tpamd_resample_uniform_device.restype = i
     L.tpamd_resample_uniform_device.argtypes = [vp, C.POINTER(_ResampleArgs), vp]
+    L.tpamd_resample_uniform_host.restype = i
+    L.tpamd_resample_uniform_host.argtypes = [vp, C.POINTER(_ResampleArgs)]
     L.tpamd_debug_copy_boundary.restype = i
     L.tpamd_debug_copy_boundary.argtypes = [vp, i, i] + [vp] * 6
     L.tpamd_debug_copy_diag.restype = i
@@ -217,7 +223,7 @@ class Engine:
             "sd_start", "sdd_start", "time_start")])
         po = _PathOutputs(*[_ptr(outputs.get(k)) for k in (
             "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
-            "max_time_increment", "status")])
+            "max_time_increment", "status", "sd2")])
         if host:
             _check(self._lib.tpamd_time_joint_paths_host(self._h, C.byref(bt), C.byref(ji),
                                                          C.byref(po)),
@@ -226,6 +232,19 @@ class Engine:
             _check(self._lib.tpamd_time_joint_paths_device(self._h, C.byref(bt), C.byref(ji),
                                                            C.byref(po), _stream_ptr(stream)),
                    "tpamd_time_joint_paths_device")
+
+    def sample_joint_paths(self, knots, control_points, path_start, delta, num_samples):
+        """Host numpy arrays -> (q, q1, q2) [B][N][D]."""
+        cp = np.ascontiguousarray(control_points, dtype=np.float64)
+        kn = np.ascontiguousarray(knots, dtype=np.float64)
+        B, P, D = cp.shape
+        ps = np.ascontiguousarray(np.broadcast_to(path_start, (B,)), dtype=np.float64)
+        dl = np.ascontiguousarray(np.broadcast_to(delta, (B,)), dtype=np.float64)
+        out = [np.zeros((B, num_samples, D)) for _ in range(3)]
+        _check(self._lib.tpamd_sample_joint_paths_host(
+            self._h, B, D, int(num_samples), P, _ptr(kn), _ptr(cp), _ptr(ps), _ptr(dl),
+            _ptr(out[0]), _ptr(out[1]), _ptr(out[2])), "tpamd_sample_joint_paths_host")
+        return tuple(out)
 
     # ------------------------------------------------------- constraint rows
     def optimize_rows(self, inputs, outputs, max_solver_loops=0, stream=None, host=False):
@@ -237,7 +256,7 @@ class Engine:
             "time_start")])
         po = _PathOutputs(*[_ptr(outputs.get(k)) for k in (
             "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
-            "max_time_increment", "status")])
+            "max_time_increment", "status", "sd2")])
         if host:
             _check(self._lib.tpamd_optimize_rows_host(self._h, C.byref(bt), C.byref(ri),
                                                       C.byref(po)), "tpamd_optimize_rows_host")

@@ -1,0 +1,236 @@
+#include "time_optimal_path_timing.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+#include "engine_handle.h"
+
+namespace trajectory_planning {
+
+using ::tpamd::compat::FailedPreconditionError;
+using ::tpamd::compat::NotFoundError;
+using ::tpamd::compat::OkStatus;
+using ::tpamd::compat::Status;
+
+namespace {
+void LogError(const char *what) { std::fprintf(stderr, "[E time_optimal_path_timing] %s\n", what); }
+}  // namespace
+
+void TimeOptimalPathProfile::SetDebugVerbosity(int) {}
+
+bool TimeOptimalPathProfile::InitSolver(int num_samples, int num_constraints) {
+  num_samples_ = num_samples;
+  num_constraints_ = num_constraints;
+  const size_t n = num_samples > 0 ? num_samples : 0;
+  time_.resize(n); s_.resize(n); sd_.resize(n); sdd_.resize(n); sd2_.resize(n);
+  last_extremal_index_ = 0;
+  solver_state_ = kAllocated;
+  return true;
+}
+
+void TimeOptimalPathProfile::SetMaxNumSolverLoops(int num_loops) { max_num_loops_ = num_loops; }
+
+// The size checks are made here; every numeric admissibility check of the reference
+// (time_optimal_path_timing.cc:169-193, :554-576) is evaluated by the engine in the
+// reference's order and reported through last_status().
+bool TimeOptimalPathProfile::SetupProblem(const std::vector<Constraint> &constraints,
+                                          Scalar s_start, Scalar s_end, Scalar sd_start,
+                                          Scalar sdd_start, Scalar time_start) {
+  if (static_cast<int>(constraints.size()) != num_samples_) {
+    LogError("Wrong sampling dimension for constraints.");
+    return false;
+  }
+  const size_t N = num_samples_, C = num_constraints_;
+  rows_a_.resize(N * C); rows_b_.resize(N * C); rows_lo_.resize(N * C); rows_hi_.resize(N * C);
+  for (size_t i = 0; i < N; i++) {
+    const Constraint &c = constraints[i];
+    if (c.size() != num_constraints_) {
+      LogError("Constraint size error.");
+      return false;
+    }
+    std::copy(c.a_coefficient(), c.a_coefficient() + C, rows_a_.begin() + i * C);
+    std::copy(c.b_coefficient(), c.b_coefficient() + C, rows_b_.begin() + i * C);
+    std::copy(c.lower(), c.lower() + C, rows_lo_.begin() + i * C);
+    std::copy(c.upper(), c.upper() + C, rows_hi_.begin() + i * C);
+    Scalar widest = -std::numeric_limits<Scalar>::max();
+    for (size_t k = 0; k < C; k++) widest = std::max(widest, c.upper((int)k) - c.lower((int)k));
+    if (widest <= 0) {
+      LogError("Infeasible bounds, at least one upper limit not > lower limit.");
+      return false;
+    }
+  }
+  if (s_start >= s_end) { LogError("s_start must be < s_end."); return false; }
+  if (sd_start < 0) { LogError("sd_start must be >= 0."); return false; }
+  for (size_t k = 0; k < N * C; k++)
+    if (rows_lo_[k] >= rows_hi_[k]) { LogError("Constraints must satisfy: lower < upper."); return false; }
+  if (num_samples_ < 2) { LogError("Error, need at least 2 samples."); return false; }
+  s_start_ = s_start; s_end_ = s_end; sd_start_ = sd_start; sdd_start_ = sdd_start;
+  time_start_ = time_start;
+  ds_ = (s_end_ - s_start_) / (num_samples_ - 1);
+  inv_ds_ = Scalar(1) / ds_;
+  solver_state_ = kProblemDefined;
+  return true;
+}
+
+bool TimeOptimalPathProfile::OptimizePathParameter() {
+  if (solver_state_ != kProblemDefined) {
+    LogError("Error, problem not defined/set up.");
+    return false;
+  }
+  tpamd_engine *engine = ::tpamd::shared_engine();
+  if (!engine) return false;
+  ::tpamd::EngineGuard guard;
+  tpamd_rows_batch batch{1, num_samples_, num_constraints_, max_num_loops_};
+  tpamd_rows_inputs in{rows_a_.data(), rows_b_.data(), rows_lo_.data(), rows_hi_.data(),
+                       &s_start_, &s_end_, &sd_start_, &sdd_start_, &time_start_};
+  int32_t status = -1, lei = 0;
+  Scalar dtmax = 0;
+  tpamd_path_outputs out{time_.data(), s_.data(), sd_.data(), sdd_.data(), nullptr, nullptr,
+                         nullptr, &lei, &dtmax, &status, sd2_.data()};
+  const int rc = tpamd_optimize_rows_host(engine, &batch, &in, &out);
+  if (rc != 0) {
+    LogError(tpamd_error_string(rc));
+    return false;
+  }
+  last_status_ = status;
+  if (status != 0) {
+    LogError(tpamd_error_string(status));
+    return false;
+  }
+  last_extremal_index_ = lei;
+  dt_max_ = dtmax;
+  FinishSolvedState();
+  return true;
+}
+
+void TimeOptimalPathProfile::AdoptSolution(int num_samples, int num_constraints, Scalar s_start,
+                                           Scalar s_end, const Scalar *time, const Scalar *s,
+                                           const Scalar *sd, const Scalar *sdd,
+                                           const Scalar *sd2, int last_extremal_index,
+                                           Scalar dt_max) {
+  InitSolver(num_samples, num_constraints);
+  s_start_ = s_start; s_end_ = s_end;
+  ds_ = (s_end - s_start) / (num_samples - 1);
+  inv_ds_ = Scalar(1) / ds_;
+  for (int i = 0; i < num_samples; i++) {
+    time_[i] = time[i]; s_[i] = s[i]; sd_[i] = sd[i]; sdd_[i] = sdd[i]; sd2_[i] = sd2[i];
+  }
+  time_start_ = time[0];
+  last_extremal_index_ = last_extremal_index;
+  dt_max_ = dt_max;
+  last_status_ = 0;
+  rows_a_.clear(); rows_b_.clear(); rows_lo_.clear(); rows_hi_.clear();
+  FinishSolvedState();
+}
+
+// low_idx_/high_idx_ bracket the strictly increasing part of time_
+// (time_optimal_path_timing.cc:468-477).
+void TimeOptimalPathProfile::FinishSolvedState() {
+  const int N = num_samples_;
+  low_idx_ = 0;
+  while ((low_idx_ < N - 2) && (time_[low_idx_] == time_[low_idx_ + 1])) low_idx_++;
+  high_idx_ = N - 1;
+  while ((high_idx_ >= 1) && (high_idx_ >= low_idx_) && (time_[high_idx_] == time_[high_idx_ - 1]))
+    high_idx_--;
+  solver_state_ = kProblemSolved;
+}
+
+Status TimeOptimalPathProfile::SolutionSatisfiesConstraints() {
+  if (solver_state_ != kProblemSolved) return FailedPreconditionError("No valid solution.");
+  if (rows_a_.empty()) return FailedPreconditionError("Constraint rows were not supplied.");
+  int violations = 0;
+  const size_t C = num_constraints_;
+  for (int i = 0; i < num_samples_; i++) {
+    const Scalar sd2 = sd2_[i];
+    for (size_t c = 0; c < C; c++) {
+      const Scalar v = rows_a_[i * C + c] * sdd_[i] + rows_b_[i * C + c] * sd2;
+      if ((v + kTiny < rows_lo_[i * C + c]) || (v - kTiny > rows_hi_[i * C + c])) ++violations;
+    }
+  }
+  if (violations > 0)
+    return NotFoundError("Number of constraint violations: " + std::to_string(violations));
+  return OkStatus();
+}
+
+TimeOptimalPathProfile::Scalar TimeOptimalPathProfile::GetMaxTimeIncrement() const {
+  if (solver_state_ != kProblemSolved) { LogError("Error, solution not yet calculated!"); return -1; }
+  return dt_max_;
+}
+
+int TimeOptimalPathProfile::SampleIndexFromTime(Scalar t) const {
+  const int N = num_samples_;
+  if (t <= time_[0]) return 0;
+  if (t >= time_[N - 1]) return N - 2;
+  // the bracket time_[k] <= t < time_[k+1] is unique for a non-decreasing array
+  int lo = low_idx_, hi = high_idx_;
+  if (!(time_[lo] <= t)) lo = 0;
+  if (!(t < time_[hi])) hi = N - 1;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) / 2;
+    if (time_[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+bool TimeOptimalPathProfile::GetPathParameterAndDerivatives(Scalar t, Scalar *s, Scalar *sd,
+                                                            Scalar *sdd) const {
+  if (solver_state_ != kProblemSolved) { LogError("Error, solution not yet calculated!"); return false; }
+  const int N = num_samples_;
+  auto sd2 = [this](int i) { return sd2_[i]; };
+  if (t <= time_[0]) {
+    *s = s_start_; *sd = sd_[0];
+    *sdd = 0.5 * inv_ds_ * (sd2(1) - sd2(0));
+    return true;
+  }
+  if (t >= time_[N - 1]) {
+    *s = s_end_; *sd = sd_[N - 1]; *sdd = 0.0;
+    return true;
+  }
+  const int k = SampleIndexFromTime(t);
+  if (time_[k] == time_[k + 1]) {
+    *s = s_[k + 1]; *sd = sd_[k + 1];
+    *sdd = 0.5 * inv_ds_ * (sd2(k + 1) - sd2(k));
+    return true;
+  }
+  const Scalar dt = t - time_[k];
+  const Scalar sda = sd_[k], sdb = sd_[k + 1];
+  if (sda > 0 || sdb > 0) {
+    Scalar ds = sda * dt + dt * dt * 0.25 * inv_ds_ * (sd2(k + 1) - sd2(k));
+    if (ds > ds_) ds = ds_;
+    if (dt < 0 || ds < 0) return false;
+    *s = std::min(s_[k] + ds, s_[k + 1]);
+    *sd = std::sqrt(sd2(k) + ds * inv_ds_ * (sd2(k + 1) - sd2(k)));
+    *sdd = 0.5 * inv_ds_ * (sd2(k + 1) - sd2(k));
+  } else {
+    *s = s_[k] + (s_[k + 1] - s_[k]) * dt / (time_[k + 1] - time_[k]);
+    *sd = 0.0; *sdd = 0.0;
+  }
+  return true;
+}
+
+int TimeOptimalPathProfile::GetPreviousIndex(Scalar t) const {
+  if (solver_state_ != kProblemSolved) { LogError("Error, solution not yet calculated!"); return -1; }
+  if (t < time_[0]) return -1;
+  if (t > time_[num_samples_ - 1]) return num_samples_ - 1;
+  return SampleIndexFromTime(t);
+}
+
+bool TimeOptimalPathProfile::GetPreviousDiscreteValues(Scalar t, Scalar *sk, Scalar *sdk,
+                                                       Scalar *sddk, Scalar *tk) const {
+  const int k = GetPreviousIndex(t);
+  if (k < 0) return false;
+  *sk = s_[k]; *sdk = sd_[k]; *sddk = sdd_[k]; *tk = time_[k];
+  return true;
+}
+
+void TimeOptimalPathProfile::FindMaxSd2Simplex(const Constraint &constr, Scalar *sd2max,
+                                               Scalar *sddmax, Scalar *sd2zero) {
+  tpamd_engine *engine = ::tpamd::shared_engine();
+  if (!engine) { *sd2max = *sddmax = *sd2zero = std::numeric_limits<Scalar>::quiet_NaN(); return; }
+  ::tpamd::EngineGuard guard;
+  tpamd_find_max_sd2_host(engine, 1, constr.size(), constr.a_coefficient(), constr.b_coefficient(),
+                          constr.lower(), constr.upper(), sd2max, sddmax, sd2zero);
+}
+
+}  // namespace trajectory_planning

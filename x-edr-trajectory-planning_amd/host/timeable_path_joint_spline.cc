@@ -1,0 +1,193 @@
+#include "timeable_path_joint_spline.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "engine_handle.h"
+
+namespace trajectory_planning {
+
+using ::tpamd::compat::InternalError;
+using ::tpamd::compat::InvalidArgumentError;
+using ::tpamd::compat::OkStatus;
+
+namespace {
+constexpr double kSmall = 1e-4;  // timeable_path_joint_spline.cc:33
+
+// Corner offset for rounding a polyline corner (splines/spline_utils.cc:25-45).
+VectorXd CornerOffset(const VectorXd &from, const VectorXd &to, double radius) {
+  const size_t n = from.size();
+  VectorXd delta(n), offset(n);
+  for (size_t i = 0; i < n; i++) delta[i] = to[i] - from[i];
+  const double norm = delta.norm();
+  for (size_t i = 0; i < n; i++) offset[i] = norm > 1e-6 ? delta[i] / norm : 0.0;
+  const double kSpacing = 4.0;  // spline_utils.h:44-46
+  if (norm > kSpacing * radius) {
+    for (size_t i = 0; i < n; i++) offset[i] = offset[i] * radius;
+  } else {
+    for (size_t i = 0; i < n; i++) offset[i] = offset[i] * (1.0 / kSpacing) * norm;
+  }
+  return offset;
+}
+
+VectorXd Plus(const VectorXd &a, const VectorXd &b) {
+  VectorXd r(a.size());
+  for (size_t i = 0; i < a.size(); i++) r[i] = a[i] + b[i];
+  return r;
+}
+}  // namespace
+
+TimeableJointSplinePath::TimeableJointSplinePath(const JointPathOptions &options)
+    : options_(options) {
+  const size_t N = options_.num_path_samples(), D = options_.num_dofs();
+  path_position_.assign(N, VectorXd(D));
+  first_path_derivative_.assign(N, VectorXd(D));
+  second_path_derivative_.assign(N, VectorXd(D));
+  constraints_.resize(N);
+  for (auto &c : constraints_) c.resize((int)(2 * D));
+  max_joint_velocity_ = VectorXd(D);
+  max_joint_acceleration_ = VectorXd(D);
+  initial_velocity_ = VectorXd(D);
+  Reset();
+}
+
+void TimeableJointSplinePath::Reset() {
+  waypoints_.clear();
+  control_points_.clear();
+  packed_control_points_.clear();
+  knots_.clear();
+  path_state_ = State::kNoPath;
+  parameter_start_ = std::numeric_limits<double>::quiet_NaN();
+  parameter_end_ = std::numeric_limits<double>::quiet_NaN();
+  initial_velocity_.setZero();
+}
+
+Status TimeableJointSplinePath::SetMaxJointVelocity(Span<const double> v) {
+  if (v.size() != options_.num_dofs()) return InvalidArgumentError("max_velocity has the wrong dimension");
+  max_joint_velocity_ = VectorXd(v.data(), v.size());
+  return OkStatus();
+}
+
+Status TimeableJointSplinePath::SetMaxJointAcceleration(Span<const double> a) {
+  if (a.size() != options_.num_dofs()) return InvalidArgumentError("max_acceleration has the wrong dimension");
+  max_joint_acceleration_ = VectorXd(a.data(), a.size());
+  return OkStatus();
+}
+
+Status TimeableJointSplinePath::SetInitialVelocity(Span<const double> v) {
+  if (v.size() != NumDofs()) return InvalidArgumentError("Velocity dimension doesn't match number of dofs.");
+  initial_velocity_ = VectorXd(v.data(), v.size());
+  return OkStatus();
+}
+
+bool TimeableJointSplinePath::CloseToEnd(double parameter) const {
+  return knots_.empty() || parameter >= knots_.back() - kSmall;
+}
+
+Status TimeableJointSplinePath::SetWaypoints(Span<const VectorXd> waypoints) {
+  for (const auto &wp : waypoints)
+    if (wp.size() != options_.num_dofs()) return InvalidArgumentError("waypoint has the wrong dimension");
+  waypoints_.assign(waypoints.begin(), waypoints.end());
+  path_state_ = State::kNewPath;
+  return FitSplineToWaypoints();
+}
+
+// Waypoints -> 3W-2 control points with rounded corners (splines/spline_utils.cc:47-102),
+// uniform degree-2 knots by running accumulation (splines/bspline_base.cc:356-381),
+// scaled by the control polygon length (timeable_path_joint_spline.cc:252-292).
+Status TimeableJointSplinePath::FitSplineToWaypoints() {
+  if (waypoints_.empty()) return InvalidArgumentError("Control point vector empty.");
+  const size_t W = waypoints_.size(), D = options_.num_dofs();
+  const double radius = options_.rounding();
+  if (W == 1) {
+    control_points_.assign(4, waypoints_.front());
+  } else {
+    control_points_.assign(3 * W - 2, VectorXd(D));
+    for (size_t i = 0; i < W; i++) control_points_[3 * i] = waypoints_[i];
+    auto &cp = control_points_;
+    for (size_t i = 1; i + 1 < W; i++) {
+      const size_t k = 3 * i;
+      cp[k + 1] = Plus(cp[k], CornerOffset(cp[k], cp[k + 3], radius));
+      cp[k - 1] = Plus(cp[k], CornerOffset(cp[k], cp[k - 3], radius));
+    }
+    cp[1] = Plus(cp[0], CornerOffset(cp[0], cp[3], radius));
+    const size_t sz = cp.size();
+    cp[sz - 2] = Plus(cp[sz - 1], CornerOffset(cp[sz - 1], cp[sz - 4], radius));
+  }
+  const size_t P = control_points_.size();
+  const size_t nk = P + kSplineOrder + 1;
+  knots_.assign(nk, 0.0);
+  const double spacing = (1.0 / (nk - 2.0 * (kSplineOrder + 1.0) + 1.0)) * (1.0 - 0.0);
+  for (size_t i = kSplineOrder + 1; i < nk - kSplineOrder - 1; i++) knots_[i] = knots_[i - 1] + spacing;
+  for (size_t i = nk - kSplineOrder - 1; i < nk; i++) knots_[i] = 1.0;
+  double length = 0.0;
+  for (size_t i = 0; i + 1 < P; i++) {
+    VectorXd diff(D);
+    for (size_t d = 0; d < D; d++) diff[d] = control_points_[i + 1][d] - control_points_[i][d];
+    length += diff.norm();
+  }
+  const double weighted = std::max(length * 1.0, 0.1);
+  for (double &k : knots_) k *= weighted;
+  packed_control_points_.resize(P * D);
+  for (size_t i = 0; i < P; i++)
+    for (size_t d = 0; d < D; d++) packed_control_points_[i * D + d] = control_points_[i][d];
+  return OkStatus();
+}
+
+void TimeableJointSplinePath::AdoptSamples(double path_start, const double *q, const double *q1,
+                                           const double *q2) {
+  const size_t N = options_.num_path_samples(), D = options_.num_dofs();
+  parameter_start_ = path_start;
+  parameter_end_ = N * options_.delta_parameter();  // sic: timeable_path_joint_spline.cc:296
+  for (size_t i = 0; i < N; i++)
+    for (size_t d = 0; d < D; d++) {
+      path_position_[i][d] = q[i * D + d];
+      first_path_derivative_[i][d] = q1[i * D + d];
+      second_path_derivative_[i][d] = q2[i * D + d];
+    }
+  path_state_ = State::kPathWasSampled;
+}
+
+Status TimeableJointSplinePath::SamplePath(const double path_start) {
+  if (knots_.empty()) return ::tpamd::compat::FailedPreconditionError("Call SetWaypoints first.");
+  tpamd_engine *engine = ::tpamd::shared_engine();
+  if (!engine) return InternalError("no GPU engine");
+  const size_t N = options_.num_path_samples(), D = options_.num_dofs();
+  std::vector<double> q(N * D), q1(N * D), q2(N * D);
+  const double delta = options_.delta_parameter();
+  {
+    ::tpamd::EngineGuard guard;
+    const int rc = tpamd_sample_joint_paths_host(engine, 1, (int)D, (int)N, num_control_points(),
+                                                 knots_.data(), packed_control_points_.data(),
+                                                 &path_start, &delta, q.data(), q1.data(), q2.data());
+    if (rc != 0) return InternalError(tpamd_error_string(rc));
+  }
+  AdoptSamples(path_start, q.data(), q1.data(), q2.data());
+  return OkStatus();
+}
+
+// timeable_path_joint_spline.cc:320-343 (only needed when a caller wants the rows; the
+// fused engine call forms them on the device).
+Status TimeableJointSplinePath::ConstraintSetup() {
+  const size_t N = options_.num_path_samples(), D = options_.num_dofs();
+  const double safety = options_.constraint_safety();
+  for (size_t idx = 0; idx < N; idx++) {
+    auto &c = constraints_[idx];
+    for (size_t dof = 0; dof < D; dof++) {
+      const double d1 = first_path_derivative_[idx][dof];
+      c.a_coefficient((int)dof) = d1;
+      c.b_coefficient((int)dof) = second_path_derivative_[idx][dof];
+      c.upper((int)dof) = max_joint_acceleration_[dof] * safety;
+      c.lower((int)dof) = -max_joint_acceleration_[dof] * safety;
+      c.a_coefficient((int)(D + dof)) = 0.0;
+      c.b_coefficient((int)(D + dof)) = d1 * d1;
+      const double v = max_joint_velocity_[dof] * safety;
+      c.upper((int)(D + dof)) = v * v;
+      c.lower((int)(D + dof)) = 0.0;
+    }
+  }
+  return OkStatus();
+}
+
+}  // namespace trajectory_planning
