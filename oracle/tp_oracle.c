@@ -930,9 +930,16 @@ int tpo_profile_optimize(tpo_profile *p) {
     } else {
       iback_hi = icrit;
     }
-    iback_lo = add_backward_extremal(p, iback_hi);
-    iforw_lo = icrit;
-    iforw_hi = add_forward_extremal(p, iforw_lo);
+    {
+      /* debug only: what running the two extremals of a loop concurrently would save */
+      const long long b0 = g_counters[1], f0 = g_counters[0];
+      iback_lo = add_backward_extremal(p, iback_hi);
+      iforw_lo = icrit;
+      iforw_hi = add_forward_extremal(p, iforw_lo);
+      const long long cb = g_counters[1] - b0, cf = g_counters[0] - f0;
+      g_counters[6] += (cb > cf) ? cb : cf;
+      g_counters[7] += (iback_hi == icrit);
+    }
     if (iback_lo > icrit_lo) return TPO_ERR_NO_CONNECTION;
     icrit_lo = iforw_hi;
   }

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import torch
 eng = importlib.import_module("x-edr-trajectory-planning_amd.engine")
 syn = importlib.import_module("x-edr-trajectory-planning_amd.synthetic")
-eng._SO = os.path.join(ROOT, "x-edr-trajectory-planning_amd", "csrc", "libtpamd_diag.so")
+eng._SO = os.path.join(ROOT, "x-edr-trajectory-planning_amd", "csrc", os.environ.get("DIAG_SO", "libtpamd_diag.so"))
 B, D, N = int(os.environ.get("DIAG_B", 1024)), 7, 2000
 E = eng.Engine(0)
 b = syn.make_joint_batch(B, D, N)
@@ -17,7 +17,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = E.debug_diag(B).astype(np.float64)
 names = {0: "fwd extremals", 1: "bwd extremals", 2: "crit search", 3: "tail", 4: "find_sdd steps",
-         5: "whole loop", 8: "n boundary fwd", 9: "n boundary bwd", 10: "n findsdd fwd", 11: "n findsdd bwd"}
+         5: "whole loop", 6: "step post part", 7: "step pre part", 8: "n boundary fwd", 9: "n boundary bwd",
+         10: "n findsdd fwd", 11: "n findsdd bwd", 12: "tile fills", 13: "tile fills w/o prefetch"}
 for k, n in names.items():
     print("%-16s mean %12.0f  min %12.0f  max %12.0f" % (n, d[:, k].mean(), d[:, k].min(), d[:, k].max()))
 nf = d[:, 10] + d[:, 11]
@@ -25,3 +26,6 @@ print("cycles per find_sdd step: %.0f" % (d[:, 4].sum() / nf.sum()))
 nb = d[:, 8] + d[:, 9]
 other = d[:, 0] + d[:, 1] - d[:, 4]
 print("extremal cycles outside find_sdd per iteration: %.0f" % (other.sum() / (nf.sum() + nb.sum())))
+iters = nf.sum() + nb.sum()
+print("SUMMARY %s: whole loop %.0f cycles/path, %.0f iterations/path, %.0f cycles/iteration" % (os.environ.get("DIAG_SO", "diag"), d[:, 5].mean(), iters / B, d[:, 5].sum() / iters))
+print("pre part per iteration: %.0f ; post part per iteration: %.0f" % (d[:, 7].sum() / (nf.sum() + nb.sum()), d[:, 6].sum() / (nf.sum() + nb.sum())))

@@ -170,9 +170,12 @@ void configure_kernels_once() {
   allow_big_lds(k_lp_rows<2>);
   allow_big_lds(k_sweep<JointSource>);
   allow_big_lds(k_sweep<GenericSource>);
-  allow_big_lds(k_sweep_joint<6>);
-  allow_big_lds(k_sweep_joint<7>);
-  allow_big_lds(k_sweep_joint<14>);
+  allow_big_lds(k_sweep_joint<6, 1>);
+  allow_big_lds(k_sweep_joint<7, 1>);
+  allow_big_lds(k_sweep_joint<14, 1>);
+  allow_big_lds(k_sweep_joint<6, 2>);
+  allow_big_lds(k_sweep_joint<7, 2>);
+  allow_big_lds(k_sweep_joint<14, 2>);
 }
 
 // The sweep launch: joint-space batches with D in {6, 7, 14} (the BASELINE.json
@@ -191,10 +194,25 @@ void launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, cons
                                const Workspace &ws, const tpamd_path_outputs *out,
                                bool force_generic) {
   const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
-#define TPAMD_LAUNCH_JOINT(DD)                                                                  \
-  hipLaunchKernelGGL((k_sweep_joint<DD>), dim3(B), dim3(64), sweep_joint_lds_bytes<DD>(N), st,  \
-                     N, max_loops, src, ws, out->time, out->s, out->sd, out->sdd,               \
-                     out->last_extremal_index, out->max_time_increment, out->status)
+  // two waves per path (backward / forward extremals of a switching point run
+  // concurrently) unless TPAMD_SWEEP_WAVES=1
+  static const int waves = [] {
+    const char *v = std::getenv("TPAMD_SWEEP_WAVES");
+    return (v && v[0] == '1') ? 1 : 2;
+  }();
+#define TPAMD_LAUNCH_JOINT(DD)                                                                   \
+  do {                                                                                           \
+    if (waves == 2)                                                                              \
+      hipLaunchKernelGGL((k_sweep_joint<DD, 2>), dim3(B), dim3(128),                             \
+                         sweep_joint_lds_bytes<DD>(N, 2), st, N, max_loops, src, ws, out->time,  \
+                         out->s, out->sd, out->sdd, out->last_extremal_index,                    \
+                         out->max_time_increment, out->status);                                  \
+    else                                                                                         \
+      hipLaunchKernelGGL((k_sweep_joint<DD, 1>), dim3(B), dim3(64),                              \
+                         sweep_joint_lds_bytes<DD>(N, 1), st, N, max_loops, src, ws, out->time,  \
+                         out->s, out->sd, out->sdd, out->last_extremal_index,                    \
+                         out->max_time_increment, out->status);                                  \
+  } while (0)
   if (!force_generic && src.D == 7) { TPAMD_LAUNCH_JOINT(7); return; }
   if (!force_generic && src.D == 6) { TPAMD_LAUNCH_JOINT(6); return; }
   if (!force_generic && src.D == 14) { TPAMD_LAUNCH_JOINT(14); return; }

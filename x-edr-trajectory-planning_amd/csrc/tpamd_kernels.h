@@ -639,53 +639,90 @@ struct Sweep {
   }
 };
 
+// Ordered prefix sum over the 64 lanes: returns carry + d_0 + d_1 + ... + d_lane, added
+// strictly left to right (the reference's time_[i] = time_[i-1] + dt, .cc:453-454). Lane L
+// takes lane L-1's running sum through a wave_shr:1 DPP move and adds its own increment;
+// after step j lanes 0..j hold their final value.
+__device__ __forceinline__ double wave_ordered_prefix(double d, double carry) {
+  double t = 0.0;
+  const int clo = __double2loint(carry), chi = __double2hiint(carry);
+#pragma unroll
+  for (int j = 0; j < 64; j++) {
+    const int lo = __builtin_amdgcn_update_dpp(clo, __double2loint(t), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(chi, __double2hiint(t), 0x138, 0xf, 0xf, false);
+    t = __hiloint2double(hi, lo) + d;
+  }
+  return t;
+}
+
 // Common tail of the sweep kernels (time_optimal_path_timing.cc:398-477): NaN
 // check, sdd fill-in at extremal intersections, start acceleration, sqrt,
 // last_extremal_index_, time integration, outputs. `status` is the outcome of the
 // switching-point loop (0, 7 or 10). sd2 is an LDS array [N]; sdd is either an LDS
-// array (copy_sdd: written out at the end) or the output row itself; dtl is an LDS
-// scratch of 64 doubles.
+// array (copy_sdd: written out at the end) or the output row itself. `pend`, when not
+// null, is an LDS bitmap of samples whose sdd entry still holds the numerator
+// 0.5*(sd2[i+-1] - sd2[i]) of a boundary-following step: the division by ds that the
+// reference performs at .cc:787/:877 is done here, off the sequential chain.
 template <class Source>
 __device__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N, int lane,
-                           int status, double *sd2, double *sdd, double *dtl, bool copy_sdd,
-                           double *t_out, double *s_out, double *sd_out, double *sdd_out,
-                           int32_t *lei_out, double *dtmax_out, int32_t *status_out) {
+                           int status, double *sd2, double *sdd, const uint32_t *pend,
+                           bool copy_sdd, double *t_out, double *s_out, double *sd_out,
+                           double *sdd_out, int32_t *lei_out, double *dtmax_out,
+                           int32_t *status_out) {
   const size_t pb = (size_t)b * N;
   const double ds = ws.ds[b];
-  Sweep<Source> S;
-  S.src = src; S.b = b; S.N = N; S.C = src.rows(); S.lane = lane;
-  S.ds = ds; S.sd2 = sd2; S.sdd = sdd;
-  S.m = ws.m + pb; S.type = ws.type + pb;
+  const double *m = ws.m + pb;
+  const int C = src.rows();
+  if (pend) {
+    for (int idx = lane; idx < N; idx += 64)
+      if (pend[idx >> 5] & (1u << (idx & 31))) sdd[idx] = sdd[idx] / ds;
+    __syncthreads();
+  }
   // NaN check and sdd fill-in (.cc:398-411); every index is independent.
   if (status == 0) {
     bool has_nan = false;
-    for (int base = 0; base < N; base += 64) {
-      const int idx = base + lane;
-      if (idx < N && isnan(sd2[idx])) has_nan = true;
-    }
+    for (int idx = lane; idx < N; idx += 64)
+      if (isnan(sd2[idx])) has_nan = true;
     if (__any(has_nan)) status = 8;
   }
   if (status == 0) {
-    const int C = S.C;
-    for (int base = 0; base < N; base += 64) {
-      const int idx = base + lane;
-      if (idx < N && isnan(sdd[idx])) {
+    for (int idx = lane; idx < N; idx += 64) {
+      if (isnan(sdd[idx])) {
+        // ComputeSddAtIntersection (.cc:722-751) for this sample alone
         const auto r = src.at(b, N, idx);
-        double cand[3];
-        int n = 0;
-        if (idx > 0 && idx < N - 1) cand[n++] = 0.25 / ds * (sd2[idx + 1] - sd2[idx - 1]);
-        if (idx < N - 1) cand[n++] = 0.5 / ds * (sd2[idx + 1] - sd2[idx]);
-        if (idx > 0) cand[n++] = 0.5 / ds * (sd2[idx] - sd2[idx - 1]);
+        const double s2 = sd2[idx];
+        const bool has_next = idx < N - 1, has_prev = idx > 0;
         double res = 0.0;
-        for (int k = 0; k < n; k++)
-          if (rows_valid(r, C, cand[k], sd2[idx])) { res = cand[k]; break; }
+        bool done = false;
+        if (has_next && has_prev) {
+          const double c = 0.25 / ds * (sd2[idx + 1] - sd2[idx - 1]);
+          if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+        }
+        if (!done && has_next) {
+          const double c = 0.5 / ds * (sd2[idx + 1] - s2);
+          if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+        }
+        if (!done && has_prev) {
+          const double c = 0.5 / ds * (s2 - sd2[idx - 1]);
+          if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+        }
         sdd[idx] = res;
       }
     }
     __syncthreads();
-    // Enforce the start acceleration if admissible (.cc:413-416).
-    const double sdd_start = ws.sdd_start[b];
-    if (S.derivs_valid(0, sdd_start, sd2[0])) S.put_sdd(0, sdd_start);
+    // Enforce the start acceleration if admissible (.cc:413-416): rows over lanes.
+    {
+      const double sdd_start = ws.sdd_start[b];
+      const auto r0 = src.at(b, N, 0);
+      const double s20 = sd2[0];
+      bool bad = false;
+      for (int i = lane; i < C; i += 64) {
+        const double v = r0.a(i) * sdd_start + r0.b(i) * s20;
+        if (v + kTiny < r0.lo(i) || v - kTiny > r0.hi(i)) bad = true;
+      }
+      if (!__any(bad) && lane == 0) sdd[0] = sdd_start;
+    }
+    __syncthreads();
     if (sd2[N - 1] != 0) status = 9;
   }
   if (status != 0) {
@@ -705,15 +742,14 @@ __device__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N,
     bool found = false;
     for (int top = start; top >= 1 && !found; top -= 64) {
       const int idx = top - lane;
-      const bool hit = (idx >= 1) && (sdd[idx] > 0.0 || fabs(sd2[idx] - S.m[idx]) < kTiny);
+      const bool hit = (idx >= 1) && (sdd[idx] > 0.0 || fabs(sd2[idx] - m[idx]) < kTiny);
       const unsigned long long mask = __ballot(hit);
       if (mask) { lei = top - (__ffsll((long long)mask) - 1); found = true; }
     }
   }
 
-  // sd = sqrt(sd2) (.cc:420), time integration (.cc:447-467). dt of 64 samples is
-  // computed in parallel; the running sum keeps the reference's left-to-right
-  // order (each lane re-adds the tile's increments in sequence).
+  // sd = sqrt(sd2) (.cc:420) and the time integral (.cc:447-467): dt of 64 samples in
+  // parallel, then the ordered prefix sum.
   const double t0 = ws.t_start[b];
   const double s0 = ws.s_start[b], s1 = ws.s_end[b];
   double tprev = t0;  // time_[base-1]
@@ -722,47 +758,34 @@ __device__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N,
     const int idx = base + lane;
     double dt = 0.0;
     bool zero_pair = false;
-    double sdv = 0.0;
+    double sdv = 0.0, s2 = 0.0;
     if (idx < N) {
-      const double s2 = sd2[idx];
+      s2 = sd2[idx];
       sdv = sqrt(s2);
       if (idx >= 1) {
         const double s2p = sd2[idx - 1];
-        if ((s2p > 0) || (s2 > 0)) {
-          dt = 2.0 * ds / (sqrt(s2p) + sdv);
-        } else {
-          zero_pair = true;
-        }
+        if ((s2p > 0) || (s2 > 0)) dt = 2.0 * ds / (sqrt(s2p) + sdv);
+        else zero_pair = true;
       }
     }
-    dtl[lane] = dt;
-    __syncthreads();
-    double t = tprev;
-    for (int k = 0; k < 64; k++) {
-      const double inc = dtl[k];
-      if (k <= lane) t += inc;
-    }
-    const double tlast = wave_bcast_f64(t, 63);
-    __syncthreads();
+    const double t = wave_ordered_prefix(dt, tprev);
+    tprev = __shfl(t, 63, 64);
     if (idx < N) {
-      t_out[pb + idx] = (idx == 0) ? t0 : t;
+      t_out[pb + idx] = t;
       sd_out[pb + idx] = sdv;
       s_out[pb + idx] = (idx == N - 1) ? s1 : ds * idx + s0;
-      ws.sd2[pb + idx] = sd2[idx];
-      if (ws.sd2_out) ws.sd2_out[pb + idx] = sd2[idx];
+      ws.sd2[pb + idx] = s2;
+      if (ws.sd2_out) ws.sd2_out[pb + idx] = s2;
       if (dt > dtmax) dtmax = dt;
     }
-    // zero acceleration across stationary pairs (.cc:463-465)
-    if (zero_pair) { sdd[idx - 1] = 0; }
-    __syncthreads();
-    if (zero_pair) { sdd[idx] = 0; }
-    __syncthreads();
-    tprev = tlast;
+    // zero acceleration across stationary pairs (.cc:463-465); both stores write 0
+    if (zero_pair) { sdd[idx - 1] = 0; sdd[idx] = 0; }
   }
   dtmax = wave_max_f64(dtmax);
-  __syncthreads();
-  if (copy_sdd)
+  if (copy_sdd) {
+    __syncthreads();
     for (int idx = lane; idx < N; idx += 64) sdd_out[pb + idx] = sdd[idx];
+  }
   if (lane == 0) {
     status_out[b] = 0;
     if (lei_out) lei_out[b] = lei;
@@ -833,8 +856,8 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
     icrit_lo = iforw_hi;
   }
   __syncthreads();
-  sweep_tail(src, ws, b, N, lane, status, lds, lds + N, lds + 2 * (size_t)N, /*copy_sdd=*/true,
-             t_out, s_out, sd_out, sdd_out, lei_out, dtmax_out, status_out);
+  sweep_tail(src, ws, b, N, lane, status, lds, lds + N, nullptr, /*copy_sdd=*/true, t_out, s_out,
+             sd_out, sdd_out, lei_out, dtmax_out, status_out);
 }
 
 // -------------------------------------------------------------- K3: epilogue

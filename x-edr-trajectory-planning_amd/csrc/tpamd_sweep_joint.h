@@ -70,8 +70,17 @@ __device__ __forceinline__ double row16_extreme(double v) {
 // Diagnostic build only (-DTPAMD_DIAG): per-path cycle counters written to ws.diag;
 // the product build contains none of this.
 #ifdef TPAMD_DIAG
-#define TPAMD_T0(var) const long long var = __builtin_readcyclecounter()
-#define TPAMD_ACC(slot, var) diag[slot] += __builtin_readcyclecounter() - (var)
+// One asm statement per stamp (s_memtime returns through lgkmcnt), fenced against the
+// scheduler on both sides (cdna_hip_programming.md section 7, "In-kernel stamps").
+__device__ __forceinline__ long long tpamd_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return (long long)t;
+}
+#define TPAMD_T0(var) const long long var = tpamd_stamp()
+#define TPAMD_ACC(slot, var) diag[slot] += tpamd_stamp() - (var)
 #define TPAMD_CNT(slot) diag[slot] += 1
 #else
 #define TPAMD_T0(var)
@@ -80,6 +89,34 @@ __device__ __forceinline__ double row16_extreme(double v) {
 #endif
 
 constexpr int kTileSamples = 32;
+
+// 16-byte pair as a native vector type: plain loads/stores that the compiler keeps in
+// registers (copies of HIP's f64x2 struct are emitted as memcpy and can pin the
+// destination in scratch).
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// K 16-byte registers as a recursive aggregate (no array, hence no indexing: every element
+// is promoted to VGPRs). load/store walk the pack with compile-time recursion.
+template <int K>
+struct RegPack {
+  f64x2 v;
+  RegPack<K - 1> rest;
+  template <int LIMIT>   // chunks beyond LIMIT are neither loaded nor stored
+  __device__ __forceinline__ void load(const f64x2 *src, int c) {
+    if (c < LIMIT) v = src[c];
+    rest.template load<LIMIT>(src, c + 64);
+  }
+  template <int LIMIT>
+  __device__ __forceinline__ void store(f64x2 *dst, int c) const {
+    if (c < LIMIT) dst[c] = v;
+    rest.template store<LIMIT>(dst, c + 64);
+  }
+};
+template <>
+struct RegPack<0> {
+  template <int LIMIT> __device__ __forceinline__ void load(const f64x2 *, int) {}
+  template <int LIMIT> __device__ __forceinline__ void store(f64x2 *, int) const {}
+};
 
 // Lane layout of one FindSddMax/FindSddMin step (D joints, 2D candidates):
 //   lane = c * PARTS + p,  c = candidate (row r = c >> 1, bound = c & 1), p = part.
@@ -116,78 +153,83 @@ struct JointSweep {
   double *sd2;            // LDS [N]
   double *tiles;          // LDS [2][kTileSamples][R]
   const uint8_t *typel;   // LDS [N] copy of the type bytes
+  uint32_t *pend;         // LDS bitmap: sdd entries that still await the division by ds
   double *sdd_g;          // global: sdd output row of this path
   const double *rec;      // global: records of this path [N][R]
   int tag0, tag1;         // tile index resident in ring slot 0 / 1 (-1: none)
-  int pf_tag;             // tile index held in the prefetch registers (-1: none)
-  double2 pf[kChunksPerLane];
   // per-lane constants (roles are folded into data so that the hot loop has no role
   // branches): idle lanes carry lim = NaN (their candidate is NaN, hence rejected) and
   // vel_hi = +inf (their velocity check never fails).
   double lim;             // the bound defining this lane's candidate
   double chk_hi[L::RPL];  // upper bounds of the acceleration rows this lane validates
   double vel_hi;          // upper bound of the velocity row this lane checks
-  int own_off;            // offsets (in double2 units) of the pairs this lane reads
+  int own_off;            // offsets (in f64x2 units) of the pairs this lane reads
   int chk_off[L::RPL];
   int vel_off;
   double row_lo, row_hi;  // AreDerivativesValid: lane j < 2D owns row j
 
   struct Rows {
-    double2 own;            // (q', q'') of the candidate's row
-    double2 chk[L::RPL];    // pairs of the rows this lane validates
-    double2 vel;            // pair of the velocity row this lane checks
+    f64x2 own;            // (q', q'') of the candidate's row
+    f64x2 chk[L::RPL];    // pairs of the rows this lane validates
+    f64x2 vel;            // pair of the velocity row this lane checks
   };
 
-  // ---- tile ring -----------------------------------------------------------
-  // Loads always cover a full tile: a partial last tile reads at most 31 records past
-  // the path's end, which is still inside the engine workspace (never used).
-  __device__ __forceinline__ void issue_tile_loads(int t) {
-    const double2 *src = reinterpret_cast<const double2 *>(rec + (size_t)t * kTileSamples * R);
-#pragma unroll
-    for (int k = 0; k < kChunksPerLane; k++) {
-      const int c = lane + 64 * k;
-      if (kChunks % 64 == 0 || k < kChunksPerLane - 1 || c < kChunks) pf[k] = src[c];
-    }
-    pf_tag = t;
+  // LDS traffic of ONE wave is processed in issue order, so lanes of the same wave see each
+  // other's LDS writes without an s_barrier; the fence only pins the compiler's order. (A
+  // workgroup barrier here would be wrong in the two-wave kernel, whose waves run
+  // different extremals.)
+  static __device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  __device__ __forceinline__ void store_tile(int slot) {
-    double2 *dst = reinterpret_cast<double2 *>(tiles + (size_t)slot * kTileSamples * R);
-#pragma unroll
-    for (int k = 0; k < kChunksPerLane; k++) {
-      const int c = lane + 64 * k;
-      if (kChunks % 64 == 0 || k < kChunksPerLane - 1 || c < kChunks) dst[c] = pf[k];
-    }
-    __syncthreads();
+
+  // ---- tile ring -----------------------------------------------------------
+  // The prefetch registers live in the calling extremal (a struct-member array is not
+  // promoted to registers). Loads always cover a full tile: a partial last tile reads at
+  // most 31 records past the path's end, still inside the engine workspace (never used).
+  struct Prefetch {
+    RegPack<kChunksPerLane> r;
+    int tag;   // tile index held in r (-1: none)
+  };
+  __device__ __forceinline__ void issue_tile_loads(int t, Prefetch &pf) const {
+    const f64x2 *src = reinterpret_cast<const f64x2 *>(rec + (size_t)t * kTileSamples * R);
+    pf.r.template load<kChunks>(src, lane);
+    pf.tag = t;
+  }
+  __device__ __forceinline__ void store_tile(int slot, const Prefetch &pf) const {
+    f64x2 *dst = reinterpret_cast<f64x2 *>(tiles + (size_t)slot * kTileSamples * R);
+    pf.r.template store<kChunks>(dst, lane);
+    wave_lds_sync();
   }
   // Make tile t resident; dir tells which neighbour tile to prefetch afterwards.
-  __device__ __forceinline__ void fill_tile(int t, int dir) {
+  __device__ __forceinline__ void fill_tile(int t, int dir, Prefetch &pf) {
     TPAMD_CNT(12);
-    if (pf_tag != t) { TPAMD_CNT(13); issue_tile_loads(t); }
-    __syncthreads();                 // earlier readers of this slot are done
-    store_tile(t & 1);               // waits for the loads, writes LDS
+    if (pf.tag != t) { TPAMD_CNT(13); issue_tile_loads(t, pf); }
+    wave_lds_sync();                 // earlier readers of this slot are done
+    store_tile(t & 1, pf);           // waits for the loads, writes LDS
     if (t & 1) tag1 = t; else tag0 = t;
     const int tn = t + dir;
-    pf_tag = -1;
-    if (tn >= 0 && tn * kTileSamples < N) issue_tile_loads(tn);
+    pf.tag = -1;
+    if (tn >= 0 && tn * kTileSamples < N) issue_tile_loads(tn, pf);
   }
-  __device__ __forceinline__ void ensure_tile(int idx, int dir) {
+  __device__ __forceinline__ void ensure_tile(int idx, int dir, Prefetch &pf) {
     const int t = idx / kTileSamples;
     const int tag = (t & 1) ? tag1 : tag0;
-    if (tag != t) fill_tile(t, dir);
+    if (tag != t) fill_tile(t, dir, pf);
   }
-  __device__ __forceinline__ const double2 *record(int idx) const {
+  __device__ __forceinline__ const f64x2 *record(int idx) const {
     // slot = (idx / 32) & 1, position = idx % 32  ==  idx & 63 in a 64-record ring
-    return reinterpret_cast<const double2 *>(tiles) + (size_t)(idx & (2 * kTileSamples - 1)) * (R / 2);
+    return reinterpret_cast<const f64x2 *>(tiles) + (size_t)(idx & (2 * kTileSamples - 1)) * (R / 2);
   }
   __device__ __forceinline__ void load_rows(int idx, Rows &r) const {
-    const double2 *p = record(idx);
+    const f64x2 *p = record(idx);
     r.own = p[own_off];
 #pragma unroll
     for (int k = 0; k < L::RPL; k++) r.chk[k] = p[chk_off[k]];
     r.vel = p[vel_off];
   }
   __device__ __forceinline__ void load_mt(int idx, double &m, int &t) const {
-    const double2 v = record(idx)[D];
+    const f64x2 v = record(idx)[D];
     m = v.x;
     t = __double2loint(v.y);
   }
@@ -196,8 +238,27 @@ struct JointSweep {
     if (lane == 0) sd2[i] = v;
     __builtin_amdgcn_wave_barrier();
   }
-  __device__ __forceinline__ void put_sdd(int i, double v) {
+  // pending: v is the numerator 0.5*(sd2 difference) of a boundary-following step; the
+  // tail divides it by ds (same operands, same result as dividing here).
+  __device__ __forceinline__ void put_sdd(int i, double v, bool pending = false) {
+#if defined(TPAMD_ABL_ST)
+    (void)i; (void)v; (void)pending;
+#elif defined(TPAMD_ABL_NOATOM)
     if (lane == 0) sdd_g[i] = v;
+#elif defined(TPAMD_ABL_ALLSTORE)
+    sdd_g[i] = v;
+#elif defined(TPAMD_ABL_ONLYATOM)
+    if (lane == 0) {
+      if (pending) atomicOr(&pend[i >> 5], 1u << (i & 31));
+      else atomicAnd(&pend[i >> 5], ~(1u << (i & 31)));
+    }
+#else
+    if (lane == 0) {
+      sdd_g[i] = v;
+      if (pending) atomicOr(&pend[i >> 5], 1u << (i & 31));
+      else atomicAnd(&pend[i >> 5], ~(1u << (i & 31)));
+    }
+#endif
   }
 
   // FindSddMax (MAX) / FindSddMin, time_optimal_path_timing.cc:638-695.
@@ -208,14 +269,26 @@ struct JointSweep {
     const double vv = (r.vel.x * r.vel.x) * s2;
     const bool vel_bad = (vv + kTiny < 0.0) | (vv - kTiny > vel_hi);
     // candidate of this lane's group
+#ifdef TPAMD_ABL_DIV
+    const double sddi = (lim - r.own.y * s2) * r.own.x;   // timing ablation: wrong results
+#else
     const double sddi = (lim - r.own.y * s2) / r.own.x;
+#endif
     bool bad = (fabs(r.own.x) < kTiny) | (sddi != sddi);
+#ifndef TPAMD_ABL_VAL
 #pragma unroll
     for (int k = 0; k < L::RPL; k++) {
       const double v = r.chk[k].x * sddi + r.chk[k].y * s2;
       bad = bad | (v + kTiny < -chk_hi[k]) | (v - kTiny > chk_hi[k]);
     }
+#endif
     double best = bad ? kSentinel : sddi;
+#ifdef TPAMD_ABL_RED
+    double res = uniform_f64(best);                       // timing ablation: wrong results
+    if (res == kSentinel) res = 0;
+    if (__ballot(vel_bad) != 0ull) res = 0;
+    return res;
+#else
     // all parts of a candidate must agree: the group keeps the sentinel if any part set it
     if (L::PARTS >= 2) best = ext2<!MAX>(best, dpp_f64<0xB1>(best));   // xor 1
     if (L::PARTS >= 4) best = ext2<!MAX>(best, dpp_f64<0x4E>(best));   // xor 2
@@ -230,6 +303,7 @@ struct JointSweep {
     if (res == kSentinel) res = 0;
     if (__ballot(vel_bad) != 0ull) res = 0;
     return res;
+#endif
   }
 
   // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
@@ -237,7 +311,7 @@ struct JointSweep {
     bool bad = false;
     if (lane < 2 * D) {
       const int d = (lane < D) ? lane : lane - D;
-      const double2 pr = *reinterpret_cast<const double2 *>(rec + (size_t)idx * R + 2 * d);
+      const f64x2 pr = *reinterpret_cast<const f64x2 *>(rec + (size_t)idx * R + 2 * d);
       const double A = (lane < D) ? pr.x : 0.0;
       const double Bc = (lane < D) ? pr.y : pr.x * pr.x;
       const double v = A * sddv + Bc * s2;
@@ -270,14 +344,31 @@ struct JointSweep {
 
   // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952)
   // otherwise. "n" = the neighbour the extremal moves to (idx+1 or idx-1).
+  // pair_signal (two-wave kernel, backward extremal only): release the partner wave, which
+  // runs the forward extremal of the same switching point, once this extremal's FIRST step
+  // is complete. Only that step can touch what the partner reads (sd2[icrit-1], sdd[icrit]);
+  // afterwards the two extremals work on disjoint index ranges.
   template <bool FWD>
-  __device__ int add_extremal(int idx_start) {
+  __device__ int add_extremal(int idx_start, bool pair_signal = false) {
     constexpr int dir = FWD ? 1 : -1;
     int idx = idx_start;
-    if (FWD ? !(idx < N - 2) : !(idx > 1)) return FWD ? N - 1 : 0;
+#define TPAMD_PAIR_SIGNAL()                                   \
+  do {                                                        \
+    if (pair_signal) {                                        \
+      __threadfence_block();                                  \
+      __syncthreads();                                        \
+      pair_signal = false;                                    \
+    }                                                         \
+  } while (0)
+    if (FWD ? !(idx < N - 2) : !(idx > 1)) {
+      TPAMD_PAIR_SIGNAL();
+      return FWD ? N - 1 : 0;
+    }
     Rows cur_rows, nxt_rows;
-    ensure_tile(idx, dir);
-    ensure_tile(idx + dir, dir);
+    Prefetch pf;
+    pf.tag = -1;
+    ensure_tile(idx, dir, pf);
+    ensure_tile(idx + dir, dir, pf);
     load_rows(idx, cur_rows);
     double cur = uniform_f64(sd2[idx]);
     double m_i, m_n;
@@ -286,24 +377,35 @@ struct JointSweep {
     load_mt(idx + dir, m_n, t_n);
     m_i = uniform_f64(m_i); m_n = uniform_f64(m_n);
     t_i = uniform_i32(t_i); t_n = uniform_i32(t_n);
+    // sd2 of the neighbour (intersection test) is read one step ahead as well: this step
+    // only writes sd2[nidx], never sd2[nidx + dir]
+    double nxt = uniform_f64(sd2[idx + dir]);
     for (;;) {
       const int nidx = idx + dir;
       const bool more = FWD ? (nidx < N - 2) : (nidx > 1);
       // stage the next step's data (1 <= nidx <= N-2, 0 <= nidx+dir <= N-1); a new tile
       // can only be entered at a tile edge
       if (((nidx + dir) & (kTileSamples - 1)) == (FWD ? 0 : kTileSamples - 1))
-        ensure_tile(nidx + dir, dir);
+        ensure_tile(nidx + dir, dir, pf);
+#ifdef TPAMD_ABL_LDS
+      nxt_rows = cur_rows;                                // timing ablation: wrong results
+      double m_nn = m_n;
+      int t_nn = t_n;
+#else
       load_rows(nidx, nxt_rows);
       double m_nn;
       int t_nn;
       load_mt(nidx + dir, m_nn, t_nn);
-      const double nxt = uniform_f64(sd2[nidx]);
+#endif
+      const double nxt_nn = sd2[nidx + dir];
       const bool on_boundary = is_tiny(cur - m_i);
       double sd2tmp, sddtmp;
+      bool pending = false;
       if (on_boundary && (t_i & kBndTrajectory) && (t_n & kBndTrajectory)) {
         TPAMD_CNT(FWD ? 8 : 9);
         sd2tmp = m_n;
-        sddtmp = FWD ? 0.5 * (sd2tmp - cur) / ds : 0.5 * (cur - sd2tmp) / ds;
+        sddtmp = FWD ? 0.5 * (sd2tmp - cur) : 0.5 * (cur - sd2tmp);   // "/ ds" in the tail
+        pending = true;
       } else {
         TPAMD_CNT(FWD ? 10 : 11);
         sddtmp = uniform_f64(find_sdd<FWD>(cur_rows, cur));
@@ -311,6 +413,7 @@ struct JointSweep {
       }
       if (!isnan(nxt) && (nxt < sd2tmp)) {
         sdd_at_intersection(idx);
+        TPAMD_PAIR_SIGNAL();
         return FWD ? N - 1 : 0;
       }
       if (sd2tmp > m_n) {
@@ -319,12 +422,17 @@ struct JointSweep {
         const bool type_invalid = t_n & (FWD ? kBndSink : kBndSource);
         const bool stop = FWD ? (type_invalid || deriv_invalid)
                               : ((type_invalid || deriv_invalid) && !(idx_start != (N - 1)));
-        if (stop) return idx;
+        if (stop) {
+          TPAMD_PAIR_SIGNAL();
+          return idx;
+        }
         sd2tmp = m_n;
         sddtmp = sdd_bound;
+        pending = false;
       }
       if (sd2tmp < 0) {
         sd2tmp = 0.0;
+        pending = false;
         if (FWD) {
           if (idx <= 1) sddtmp = 0.0; else sddtmp = -sd2[idx - 1] / ds;
         } else {
@@ -332,7 +440,8 @@ struct JointSweep {
         }
       }
       put_sd2(nidx, sd2tmp);
-      put_sdd(idx, sddtmp);
+      put_sdd(idx, sddtmp, pending);
+      TPAMD_PAIR_SIGNAL();
       if (!more) return FWD ? N - 1 : 0;
       idx = nidx;
       cur = sd2tmp;
@@ -340,8 +449,10 @@ struct JointSweep {
       t_i = t_n;
       m_n = uniform_f64(m_nn);
       t_n = uniform_i32(t_nn);
+      nxt = uniform_f64(nxt_nn);
       cur_rows = nxt_rows;
     }
+#undef TPAMD_PAIR_SIGNAL
   }
 
   // NextCriticalPoint, .cc:697-720, as two wave-parallel scans over the LDS copies of
@@ -379,25 +490,32 @@ struct JointSweep {
   }
 };
 
-// Dynamic LDS (bytes): sd2[N]*8 | dt[64]*8 | tiles 2*32*R*8 | type copy N (padded to 16)
+// Dynamic LDS (bytes): sd2[N]*8 | tile rings WAVES*2*32*R*8 | pending bitmap ((N+31)/32
+// words, padded to 16 B) | type copy N (padded to 16) | exchange words 16 B
 template <int D>
-__host__ __device__ inline size_t sweep_joint_lds_bytes(int N) {
-  return (size_t)N * 8 + 64 * 8 + 2 * (size_t)kTileSamples * (2 * D + 2) * 8 +
-         (((size_t)N + 15) / 16) * 16;
+__host__ __device__ inline size_t sweep_joint_lds_bytes(int N, int waves) {
+  return (size_t)N * 8 + (size_t)waves * 2 * kTileSamples * (2 * D + 2) * 8 +
+         ((((size_t)N + 31) / 32 * 4 + 15) / 16) * 16 + (((size_t)N + 15) / 16) * 16 + 16;
 }
 
-template <int D>
-__global__ void __launch_bounds__(64)
+// WAVES = 1: one wave runs everything. WAVES = 2: wave 0 runs the backward extremals and
+// the tail, wave 1 the forward extremals; within one switching-point loop the two
+// extremals run concurrently (they are data-independent after the backward extremal's
+// first step, see add_extremal). Both waves keep identical copies of the loop scalars.
+template <int D, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
 k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
               double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
               int32_t *status_out) {
   extern __shared__ double lds[];
   const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int w = (WAVES == 2) ? uniform_i32((int)(threadIdx.x >> 6)) : 0;
+  const int tid = threadIdx.x;
   const size_t pb = (size_t)b * N;
   const uint32_t bits = ws.err_bits[b];
   if (bits) {
-    if (lane == 0) {
+    if (tid == 0) {
       status_out[b] = status_from_bits(bits);
       if (lei_out) lei_out[b] = 0;
       if (dtmax_out) dtmax_out[b] = -1.0;
@@ -410,13 +528,15 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   S.ds = ws.ds[b];
   S.two_ds = 2.0 * S.ds;
   S.sd2 = lds;
-  double *dtl = lds + N;
-  S.tiles = dtl + 64;
-  uint8_t *typel = reinterpret_cast<uint8_t *>(S.tiles + 2 * kTileSamples * JS::R);
+  S.tiles = lds + N + (size_t)w * 2 * kTileSamples * JS::R;
+  S.pend = reinterpret_cast<uint32_t *>(lds + N + (size_t)WAVES * 2 * kTileSamples * JS::R);
+  const int pend_words = (N + 31) / 32;
+  uint8_t *typel = reinterpret_cast<uint8_t *>(S.pend) + ((pend_words * 4 + 15) / 16) * 16;
   S.typel = typel;
+  int *xchg = reinterpret_cast<int *>(typel + ((N + 15) / 16) * 16);
   S.sdd_g = sdd_out + pb;
   S.rec = src.q12 + pb * JS::R;
-  S.tag0 = -1; S.tag1 = -1; S.pf_tag = -1;
+  S.tag0 = -1; S.tag1 = -1;
   const double *lim_lo = src.lim + (size_t)b * 4 * D, *lim_hi = lim_lo + 2 * D;
   {
     typedef JointLayout<D> L;
@@ -444,13 +564,14 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   double *sd2 = S.sd2;
   const double sd_start = ws.sd_start[b];
   const uint8_t *type_g = ws.type + pb;
-  for (int i = lane; i < N; i += 64) {
+  for (int i = tid; i < N; i += 64 * WAVES) {
     sd2[i] = qnan();
     S.sdd_g[i] = qnan();
     typel[i] = type_g[i];
   }
+  for (int i = tid; i < pend_words; i += 64 * WAVES) S.pend[i] = 0u;
   __syncthreads();
-  if (lane == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
+  if (tid == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
   __syncthreads();
 
   int status = 0;
@@ -460,19 +581,30 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   for (int k = 0; k < 16; k++) diag[k] = 0;
 #endif
   TPAMD_T0(t_all);
-  {
-    TPAMD_T0(t0);
+  // First pair: the forward extremal from 0 may run into the backward one from N-1, so the
+  // two are sequential (time_optimal_path_timing.cc:325-326).
+  if (WAVES == 1) {
     iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi));
-    TPAMD_ACC(1, t0);
-  }
-  {
-    TPAMD_T0(t0);
     iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo));
-    TPAMD_ACC(0, t0);
+  } else {
+    if (w == 0) {
+      const int r = S.template add_extremal<false>(iback_hi);
+      if (lane == 0) xchg[0] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (w == 1) {
+      const int r = S.template add_extremal<true>(iforw_lo);
+      if (lane == 0) xchg[1] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+    iback_lo = uniform_i32(xchg[0]);
+    iforw_hi = uniform_i32(xchg[1]);
   }
   icrit_hi = iback_lo;
   if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
-    S.put_sd2(icrit_hi, qnan());
+    if (w == 0) S.put_sd2(icrit_hi, qnan());
     icrit_hi++;
     iback_lo++;
   }
@@ -480,47 +612,76 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   const double *m_g = ws.m + pb;
   for (int loop = 0; loop < max_loops; loop++) {
     if (iforw_hi >= icrit_hi) break;
+    if (WAVES == 2) __syncthreads();   // sd2 writes of the other wave / the NaN mark are visible
     {
       TPAMD_T0(t0);
       icrit = uniform_i32(S.next_critical_point(icrit_lo, icrit_hi));
       TPAMD_ACC(2, t0);
     }
     if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
-    if (icrit > 0 && icrit < N - 1) S.put_sd2(icrit, m_g[icrit]);
+    if (WAVES == 2) __syncthreads();   // both waves finished reading sd2 before the marks below
+    if (icrit > 0 && icrit < N - 1 && w == 0) S.put_sd2(icrit, m_g[icrit]);
     if (icrit < 1) { status = 10; break; }
     if (m_g[icrit - 1] <= m_g[icrit]) {
       iback_hi = icrit - 1;
-      S.put_sd2(icrit - 1, m_g[icrit - 1]);
+      if (w == 0) S.put_sd2(icrit - 1, m_g[icrit - 1]);
     } else {
       iback_hi = icrit;
     }
-    {
-      TPAMD_T0(t0);
-      iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi));
-      TPAMD_ACC(1, t0);
-    }
     iforw_lo = icrit;
-    {
-      TPAMD_T0(t0);
-      iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo));
-      TPAMD_ACC(0, t0);
+    if (WAVES == 1) {
+      {
+        TPAMD_T0(t0);
+        iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi));
+        TPAMD_ACC(1, t0);
+      }
+      {
+        TPAMD_T0(t0);
+        iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo));
+        TPAMD_ACC(0, t0);
+      }
+    } else {
+      __syncthreads();                 // A: the marks are visible to the forward wave
+      if (w == 0) {
+        TPAMD_T0(t0);
+        const int r = S.template add_extremal<false>(iback_hi, /*pair_signal=*/true);   // B inside
+        if (lane == 0) xchg[0] = r;
+        TPAMD_ACC(1, t0);
+      } else {
+        __syncthreads();               // B: the backward extremal's first step is done
+        TPAMD_T0(t0);
+        const int r = S.template add_extremal<true>(iforw_lo);
+        if (lane == 0) xchg[1] = r;
+        TPAMD_ACC(0, t0);
+      }
+      __threadfence_block();
+      __syncthreads();                 // C
+      iback_lo = uniform_i32(xchg[0]);
+      iforw_hi = uniform_i32(xchg[1]);
     }
     if (iback_lo > icrit_lo) { status = 7; break; }
     icrit_lo = iforw_hi;
   }
   TPAMD_ACC(5, t_all);
-  // sdd_ was written with plain global stores by lane 0; make it visible to all lanes
+  // sdd_ was written with plain global stores; make it visible to all lanes of the tail
   __threadfence_block();
   __syncthreads();
+#ifdef TPAMD_DIAG
+  if (lane == 0 && ws.diag && w == WAVES - 1)
+    for (int k = 0; k < 16; k++)
+      if (WAVES == 1 || k == 0 || k >= 8) ws.diag[(size_t)b * 16 + k] = S.diag[k];
+#endif
+  if (w != 0) return;
   {
     TPAMD_T0(t0);
-    sweep_tail(src, ws, b, N, lane, status, sd2, S.sdd_g, dtl, /*copy_sdd=*/false, t_out, s_out,
+    sweep_tail(src, ws, b, N, lane, status, sd2, S.sdd_g, S.pend, /*copy_sdd=*/false, t_out, s_out,
                sd_out, sdd_out, lei_out, dtmax_out, status_out);
     TPAMD_ACC(3, t0);
   }
 #ifdef TPAMD_DIAG
   if (lane == 0 && ws.diag)
-    for (int k = 0; k < 16; k++) ws.diag[(size_t)b * 16 + k] = S.diag[k];
+    for (int k = 0; k < 16; k++)
+      if (WAVES == 1 || (k != 0 && k < 8)) ws.diag[(size_t)b * 16 + k] = S.diag[k];
 #endif
 }
 
