@@ -243,6 +243,18 @@ struct SlotSet {
   }
 };
 
+// Cheap screen for the LP's vertex searches. The exact test on a slot is
+//   tmp < hi_lim && tmp > lo_lim   with   tmp = num * (1 / den)   (two roundings).
+// tmp_apx = num * rcp(den) uses the hardware reciprocal estimate (v_rcp_f64, relative
+// error far below 1e-6); a slot whose estimate lies outside the window widened by 1e-6
+// relative cannot pass the exact test, so its IEEE division is skipped. A NaN estimate
+// never skips.
+__device__ __forceinline__ bool lp_cannot_pass(double num, double den, double lo_lim,
+                                               double hi_lim) {
+  const double tmp_apx = num * __builtin_amdgcn_rcp(den);
+  return (tmp_apx > hi_lim + fabs(hi_lim) * 1e-6) || (tmp_apx < lo_lim - fabs(lo_lim) * 1e-6);
+}
+
 template <class R>
 __device__ __forceinline__ bool lp_pair_optimal(const R &r, int s1, int s2) {
   const int first = s1 >> 1, second = s2 >> 1;
@@ -274,6 +286,7 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
     const double Bc = r.b(c);
     if (fabs(Bc) < kTiny) continue;
     if (Bc > kTiny) {
+      if (lp_cannot_pass(r.hi(c), Bc, 0.0, sd2 + kTiny)) continue;
       const double invB = 1.0 / Bc;
       const double tmp = r.hi(c) * invB;
       if (tmp < (sd2 + kTiny) && tmp > 0) {
@@ -282,6 +295,7 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
         sd2 = tmp;
       }
     } else if (Bc < -kTiny) {
+      if (lp_cannot_pass(r.lo(c), Bc, 0.0, sd2 + kTiny)) continue;
       const double invB = 1.0 / Bc;
       const double tmp = r.lo(c) * invB;
       if (tmp < (sd2 + kTiny) && tmp > 0) {
@@ -343,8 +357,9 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
       const double Ac = r.a(c);
       const double Bc = Ac * b + r.b(c);
       if (fabs(Bc) < kTiny) continue;
-      const double invB = 1.0 / Bc;
       const double lim = (s & 1) ? r.lo(c) : r.hi(c);
+      if (lp_cannot_pass(lim - Ac * a, Bc, sd2, next_sd2 + kTiny)) continue;
+      const double invB = 1.0 / Bc;
       const double tmp = (lim - Ac * a) * invB;
       if (tmp < (next_sd2 + kTiny) && tmp > sd2) {
         if (tmp < next_sd2 - kTiny) act.clear();

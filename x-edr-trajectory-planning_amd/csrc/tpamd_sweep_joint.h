@@ -153,7 +153,6 @@ struct JointSweep {
   double *sd2;            // LDS [N]
   double *tiles;          // LDS [2][kTileSamples][R]
   const uint8_t *typel;   // LDS [N] copy of the type bytes
-  uint32_t *pend;         // LDS bitmap: sdd entries that still await the division by ds
   double *sdd_g;          // global: sdd output row of this path
   const double *rec;      // global: records of this path [N][R]
   int tag0, tag1;         // tile index resident in ring slot 0 / 1 (-1: none)
@@ -238,27 +237,8 @@ struct JointSweep {
     if (lane == 0) sd2[i] = v;
     __builtin_amdgcn_wave_barrier();
   }
-  // pending: v is the numerator 0.5*(sd2 difference) of a boundary-following step; the
-  // tail divides it by ds (same operands, same result as dividing here).
-  __device__ __forceinline__ void put_sdd(int i, double v, bool pending = false) {
-#if defined(TPAMD_ABL_ST)
-    (void)i; (void)v; (void)pending;
-#elif defined(TPAMD_ABL_NOATOM)
+  __device__ __forceinline__ void put_sdd(int i, double v) {
     if (lane == 0) sdd_g[i] = v;
-#elif defined(TPAMD_ABL_ALLSTORE)
-    sdd_g[i] = v;
-#elif defined(TPAMD_ABL_ONLYATOM)
-    if (lane == 0) {
-      if (pending) atomicOr(&pend[i >> 5], 1u << (i & 31));
-      else atomicAnd(&pend[i >> 5], ~(1u << (i & 31)));
-    }
-#else
-    if (lane == 0) {
-      sdd_g[i] = v;
-      if (pending) atomicOr(&pend[i >> 5], 1u << (i & 31));
-      else atomicAnd(&pend[i >> 5], ~(1u << (i & 31)));
-    }
-#endif
   }
 
   // FindSddMax (MAX) / FindSddMin, time_optimal_path_timing.cc:638-695.
@@ -269,26 +249,14 @@ struct JointSweep {
     const double vv = (r.vel.x * r.vel.x) * s2;
     const bool vel_bad = (vv + kTiny < 0.0) | (vv - kTiny > vel_hi);
     // candidate of this lane's group
-#ifdef TPAMD_ABL_DIV
-    const double sddi = (lim - r.own.y * s2) * r.own.x;   // timing ablation: wrong results
-#else
     const double sddi = (lim - r.own.y * s2) / r.own.x;
-#endif
     bool bad = (fabs(r.own.x) < kTiny) | (sddi != sddi);
-#ifndef TPAMD_ABL_VAL
 #pragma unroll
     for (int k = 0; k < L::RPL; k++) {
       const double v = r.chk[k].x * sddi + r.chk[k].y * s2;
       bad = bad | (v + kTiny < -chk_hi[k]) | (v - kTiny > chk_hi[k]);
     }
-#endif
     double best = bad ? kSentinel : sddi;
-#ifdef TPAMD_ABL_RED
-    double res = uniform_f64(best);                       // timing ablation: wrong results
-    if (res == kSentinel) res = 0;
-    if (__ballot(vel_bad) != 0ull) res = 0;
-    return res;
-#else
     // all parts of a candidate must agree: the group keeps the sentinel if any part set it
     if (L::PARTS >= 2) best = ext2<!MAX>(best, dpp_f64<0xB1>(best));   // xor 1
     if (L::PARTS >= 4) best = ext2<!MAX>(best, dpp_f64<0x4E>(best));   // xor 2
@@ -303,7 +271,6 @@ struct JointSweep {
     if (res == kSentinel) res = 0;
     if (__ballot(vel_bad) != 0ull) res = 0;
     return res;
-#endif
   }
 
   // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
@@ -344,14 +311,24 @@ struct JointSweep {
 
   // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952)
   // otherwise. "n" = the neighbour the extremal moves to (idx+1 or idx-1).
-  // pair_signal (two-wave kernel, backward extremal only): release the partner wave, which
-  // runs the forward extremal of the same switching point, once this extremal's FIRST step
-  // is complete. Only that step can touch what the partner reads (sd2[icrit-1], sdd[icrit]);
-  // afterwards the two extremals work on disjoint index ranges.
+  // Loop-carried scalars of an extremal (all wave-uniform).
+  struct Carry {
+    int idx;        // current sample
+    double cur;     // sd2_[idx]
+    double m_i;     // sd2_max[idx]
+    double m_n;     // sd2_max[idx + dir]
+    double nxt;     // sd2_[idx + dir] as left by earlier extremals (NaN: not visited)
+    int t_i, t_n;   // type[idx], type[idx + dir]
+  };
+  static constexpr int kContinue = -2;
+
+  // One step of AddForwardExtremal (.cc:774-855) / AddBackwardExtremal (.cc:864-950): uses
+  // the rows in `use`, stages the next step's rows into `stage`. Returns kContinue or the
+  // extremal's return value. pair_signal: see add_extremal.
   template <bool FWD>
-  __device__ int add_extremal(int idx_start, bool pair_signal = false) {
+  __device__ __forceinline__ int extremal_step(Carry &c, const Rows &use, Rows &stage, Prefetch &pf,
+                                               int idx_start, bool &pair_signal) {
     constexpr int dir = FWD ? 1 : -1;
-    int idx = idx_start;
 #define TPAMD_PAIR_SIGNAL()                                   \
   do {                                                        \
     if (pair_signal) {                                        \
@@ -360,99 +337,109 @@ struct JointSweep {
       pair_signal = false;                                    \
     }                                                         \
   } while (0)
-    if (FWD ? !(idx < N - 2) : !(idx > 1)) {
+    const int idx = c.idx;
+    const int nidx = idx + dir;
+    const bool more = FWD ? (nidx < N - 2) : (nidx > 1);
+    // stage the next step's data (1 <= nidx <= N-2, 0 <= nidx+dir <= N-1); a new tile can
+    // only be entered at a tile edge
+    if (((nidx + dir) & (kTileSamples - 1)) == (FWD ? 0 : kTileSamples - 1))
+      ensure_tile(nidx + dir, dir, pf);
+    load_rows(nidx, stage);
+    double m_nn;
+    int t_nn;
+    load_mt(nidx + dir, m_nn, t_nn);
+    const double nxt_nn = sd2[nidx + dir];   // this step only writes sd2[nidx]
+    const double cur = c.cur, m_i = c.m_i, m_n = c.m_n, nxt = c.nxt;
+    const bool on_boundary = is_tiny(cur - m_i);
+    double sd2tmp, sddtmp;
+    if (on_boundary && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {
+      TPAMD_CNT(FWD ? 8 : 9);
+      sd2tmp = m_n;
+      sddtmp = FWD ? 0.5 * (sd2tmp - cur) / ds : 0.5 * (cur - sd2tmp) / ds;
+    } else {
+      TPAMD_CNT(FWD ? 10 : 11);
+      sddtmp = uniform_f64(find_sdd<FWD>(use, cur));
+      sd2tmp = FWD ? cur + two_ds * sddtmp : cur - two_ds * sddtmp;
+    }
+    if (!isnan(nxt) && (nxt < sd2tmp)) {
+      sdd_at_intersection(idx);
       TPAMD_PAIR_SIGNAL();
       return FWD ? N - 1 : 0;
     }
-    Rows cur_rows, nxt_rows;
+    if (sd2tmp > m_n) {
+      const double sdd_bound = FWD ? 0.5 * (m_n - cur) / ds : 0.5 * (cur - m_n) / ds;
+      const bool deriv_invalid = !derivs_valid(idx, sdd_bound, FWD ? m_i : cur);
+      const bool type_invalid = c.t_n & (FWD ? kBndSink : kBndSource);
+      const bool stop = FWD ? (type_invalid || deriv_invalid)
+                            : ((type_invalid || deriv_invalid) && !(idx_start != (N - 1)));
+      if (stop) {
+        TPAMD_PAIR_SIGNAL();
+        return idx;
+      }
+      sd2tmp = m_n;
+      sddtmp = sdd_bound;
+    }
+    if (sd2tmp < 0) {
+      sd2tmp = 0.0;
+      if (FWD) {
+        if (idx <= 1) sddtmp = 0.0; else sddtmp = -sd2[idx - 1] / ds;
+      } else {
+        if (idx < N - 1) sddtmp = sd2[idx + 1] / ds; else sddtmp = 0.0;
+      }
+    }
+    put_sd2(nidx, sd2tmp);
+    put_sdd(idx, sddtmp);
+    TPAMD_PAIR_SIGNAL();
+    if (!more) return FWD ? N - 1 : 0;
+    c.idx = nidx;
+    c.cur = sd2tmp;
+    c.m_i = m_n;
+    c.t_i = c.t_n;
+    c.m_n = uniform_f64(m_nn);
+    c.t_n = uniform_i32(t_nn);
+    c.nxt = uniform_f64(nxt_nn);
+    return kContinue;
+#undef TPAMD_PAIR_SIGNAL
+  }
+
+  // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952) otherwise.
+  // pair_signal (two-wave kernel, backward extremal only): release the partner wave, which
+  // runs the forward extremal of the same switching point, once this extremal's FIRST step
+  // is complete. Only that step can touch what the partner reads (sd2[icrit-1], sdd[icrit]);
+  // afterwards the two extremals work on disjoint index ranges.
+  // The loop is unrolled by two so that the two row sets swap roles without copies.
+  template <bool FWD>
+  __device__ int add_extremal(int idx_start, bool pair_signal = false) {
+    constexpr int dir = FWD ? 1 : -1;
+    if (FWD ? !(idx_start < N - 2) : !(idx_start > 1)) {
+      if (pair_signal) {
+        __threadfence_block();
+        __syncthreads();
+      }
+      return FWD ? N - 1 : 0;
+    }
+    Rows rows_a, rows_b;
     Prefetch pf;
     pf.tag = -1;
-    ensure_tile(idx, dir, pf);
-    ensure_tile(idx + dir, dir, pf);
-    load_rows(idx, cur_rows);
-    double cur = uniform_f64(sd2[idx]);
-    double m_i, m_n;
-    int t_i, t_n;
-    load_mt(idx, m_i, t_i);
-    load_mt(idx + dir, m_n, t_n);
-    m_i = uniform_f64(m_i); m_n = uniform_f64(m_n);
-    t_i = uniform_i32(t_i); t_n = uniform_i32(t_n);
-    // sd2 of the neighbour (intersection test) is read one step ahead as well: this step
-    // only writes sd2[nidx], never sd2[nidx + dir]
-    double nxt = uniform_f64(sd2[idx + dir]);
+    Carry c;
+    c.idx = idx_start;
+    ensure_tile(idx_start, dir, pf);
+    ensure_tile(idx_start + dir, dir, pf);
+    load_rows(idx_start, rows_a);
+    c.cur = uniform_f64(sd2[idx_start]);
+    double m0, m1;
+    int t0, t1;
+    load_mt(idx_start, m0, t0);
+    load_mt(idx_start + dir, m1, t1);
+    c.m_i = uniform_f64(m0); c.m_n = uniform_f64(m1);
+    c.t_i = uniform_i32(t0); c.t_n = uniform_i32(t1);
+    c.nxt = uniform_f64(sd2[idx_start + dir]);
     for (;;) {
-      const int nidx = idx + dir;
-      const bool more = FWD ? (nidx < N - 2) : (nidx > 1);
-      // stage the next step's data (1 <= nidx <= N-2, 0 <= nidx+dir <= N-1); a new tile
-      // can only be entered at a tile edge
-      if (((nidx + dir) & (kTileSamples - 1)) == (FWD ? 0 : kTileSamples - 1))
-        ensure_tile(nidx + dir, dir, pf);
-#ifdef TPAMD_ABL_LDS
-      nxt_rows = cur_rows;                                // timing ablation: wrong results
-      double m_nn = m_n;
-      int t_nn = t_n;
-#else
-      load_rows(nidx, nxt_rows);
-      double m_nn;
-      int t_nn;
-      load_mt(nidx + dir, m_nn, t_nn);
-#endif
-      const double nxt_nn = sd2[nidx + dir];
-      const bool on_boundary = is_tiny(cur - m_i);
-      double sd2tmp, sddtmp;
-      bool pending = false;
-      if (on_boundary && (t_i & kBndTrajectory) && (t_n & kBndTrajectory)) {
-        TPAMD_CNT(FWD ? 8 : 9);
-        sd2tmp = m_n;
-        sddtmp = FWD ? 0.5 * (sd2tmp - cur) : 0.5 * (cur - sd2tmp);   // "/ ds" in the tail
-        pending = true;
-      } else {
-        TPAMD_CNT(FWD ? 10 : 11);
-        sddtmp = uniform_f64(find_sdd<FWD>(cur_rows, cur));
-        sd2tmp = FWD ? cur + two_ds * sddtmp : cur - two_ds * sddtmp;
-      }
-      if (!isnan(nxt) && (nxt < sd2tmp)) {
-        sdd_at_intersection(idx);
-        TPAMD_PAIR_SIGNAL();
-        return FWD ? N - 1 : 0;
-      }
-      if (sd2tmp > m_n) {
-        const double sdd_bound = FWD ? 0.5 * (m_n - cur) / ds : 0.5 * (cur - m_n) / ds;
-        const bool deriv_invalid = !derivs_valid(idx, sdd_bound, FWD ? m_i : cur);
-        const bool type_invalid = t_n & (FWD ? kBndSink : kBndSource);
-        const bool stop = FWD ? (type_invalid || deriv_invalid)
-                              : ((type_invalid || deriv_invalid) && !(idx_start != (N - 1)));
-        if (stop) {
-          TPAMD_PAIR_SIGNAL();
-          return idx;
-        }
-        sd2tmp = m_n;
-        sddtmp = sdd_bound;
-        pending = false;
-      }
-      if (sd2tmp < 0) {
-        sd2tmp = 0.0;
-        pending = false;
-        if (FWD) {
-          if (idx <= 1) sddtmp = 0.0; else sddtmp = -sd2[idx - 1] / ds;
-        } else {
-          if (idx < N - 1) sddtmp = sd2[idx + 1] / ds; else sddtmp = 0.0;
-        }
-      }
-      put_sd2(nidx, sd2tmp);
-      put_sdd(idx, sddtmp, pending);
-      TPAMD_PAIR_SIGNAL();
-      if (!more) return FWD ? N - 1 : 0;
-      idx = nidx;
-      cur = sd2tmp;
-      m_i = m_n;
-      t_i = t_n;
-      m_n = uniform_f64(m_nn);
-      t_n = uniform_i32(t_nn);
-      nxt = uniform_f64(nxt_nn);
-      cur_rows = nxt_rows;
+      int r = extremal_step<FWD>(c, rows_a, rows_b, pf, idx_start, pair_signal);
+      if (r != kContinue) return r;
+      r = extremal_step<FWD>(c, rows_b, rows_a, pf, idx_start, pair_signal);
+      if (r != kContinue) return r;
     }
-#undef TPAMD_PAIR_SIGNAL
   }
 
   // NextCriticalPoint, .cc:697-720, as two wave-parallel scans over the LDS copies of
@@ -490,12 +477,12 @@ struct JointSweep {
   }
 };
 
-// Dynamic LDS (bytes): sd2[N]*8 | tile rings WAVES*2*32*R*8 | pending bitmap ((N+31)/32
-// words, padded to 16 B) | type copy N (padded to 16) | exchange words 16 B
+// Dynamic LDS (bytes): sd2[N]*8 | tile rings WAVES*2*32*R*8 | type copy N (padded to 16) |
+// exchange words 16 B
 template <int D>
 __host__ __device__ inline size_t sweep_joint_lds_bytes(int N, int waves) {
   return (size_t)N * 8 + (size_t)waves * 2 * kTileSamples * (2 * D + 2) * 8 +
-         ((((size_t)N + 31) / 32 * 4 + 15) / 16) * 16 + (((size_t)N + 15) / 16) * 16 + 16;
+         (((size_t)N + 15) / 16) * 16 + 16;
 }
 
 // WAVES = 1: one wave runs everything. WAVES = 2: wave 0 runs the backward extremals and
@@ -529,9 +516,7 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   S.two_ds = 2.0 * S.ds;
   S.sd2 = lds;
   S.tiles = lds + N + (size_t)w * 2 * kTileSamples * JS::R;
-  S.pend = reinterpret_cast<uint32_t *>(lds + N + (size_t)WAVES * 2 * kTileSamples * JS::R);
-  const int pend_words = (N + 31) / 32;
-  uint8_t *typel = reinterpret_cast<uint8_t *>(S.pend) + ((pend_words * 4 + 15) / 16) * 16;
+  uint8_t *typel = reinterpret_cast<uint8_t *>(lds + N + (size_t)WAVES * 2 * kTileSamples * JS::R);
   S.typel = typel;
   int *xchg = reinterpret_cast<int *>(typel + ((N + 15) / 16) * 16);
   S.sdd_g = sdd_out + pb;
@@ -569,7 +554,6 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
     S.sdd_g[i] = qnan();
     typel[i] = type_g[i];
   }
-  for (int i = tid; i < pend_words; i += 64 * WAVES) S.pend[i] = 0u;
   __syncthreads();
   if (tid == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
   __syncthreads();
@@ -674,7 +658,7 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   if (w != 0) return;
   {
     TPAMD_T0(t0);
-    sweep_tail(src, ws, b, N, lane, status, sd2, S.sdd_g, S.pend, /*copy_sdd=*/false, t_out, s_out,
+    sweep_tail(src, ws, b, N, lane, status, sd2, S.sdd_g, nullptr, /*copy_sdd=*/false, t_out, s_out,
                sd_out, sdd_out, lei_out, dtmax_out, status_out);
     TPAMD_ACC(3, t0);
   }
