@@ -664,7 +664,7 @@ __device__ __forceinline__ double wave_ordered_prefix(double d, double carry) {
 // 0.5*(sd2[i+-1] - sd2[i]) of a boundary-following step: the division by ds that the
 // reference performs at .cc:787/:877 is done here, off the sequential chain.
 template <class Source>
-__device__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N, int lane,
+__device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N, int lane,
                            int status, double *sd2, double *sdd, const uint32_t *pend,
                            bool copy_sdd, double *t_out, double *s_out, double *sd_out,
                            double *sdd_out, int32_t *lei_out, double *dtmax_out,

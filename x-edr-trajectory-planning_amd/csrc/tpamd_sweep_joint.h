@@ -154,6 +154,7 @@ struct JointSweep {
   double *tiles;          // LDS [2][kTileSamples][R]
   const uint8_t *typel;   // LDS [N] copy of the type bytes
   double *sdd_g;          // global: sdd output row of this path
+  const double *m_g;      // global: final sd2_max of this path [N]
   const double *rec;      // global: records of this path [N][R]
   int tag0, tag1;         // tile index resident in ring slot 0 / 1 (-1: none)
   // per-lane constants (roles are folded into data so that the hot loop has no role
@@ -274,7 +275,7 @@ struct JointSweep {
   }
 
   // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
-  __device__ bool derivs_valid(int idx, double sddv, double s2) const {
+  __device__ __forceinline__ bool derivs_valid(int idx, double sddv, double s2) const {
     bool bad = false;
     if (lane < 2 * D) {
       const int d = (lane < D) ? lane : lane - D;
@@ -402,44 +403,115 @@ struct JointSweep {
 #undef TPAMD_PAIR_SIGNAL
   }
 
+  // Boundary following, 64 steps at a time. While an extremal rides the boundary curve
+  // (sd2[idx] on the curve, type[idx] and type[idx+dir] both "trajectory",
+  // .cc:778-787 / :868-877) every step just copies the curve: sd2[idx+dir] = sd2_max[idx+dir],
+  // sdd[idx] = 0.5*(difference)/ds, and the next sample is on the curve again by
+  // construction. Whether step k of such a run happens depends only on data known
+  // beforehand (types, the curve, sd2 values left by earlier extremals), so lane k
+  // evaluates step k: the run is the leading block of eligible lanes. Steps that the
+  // scalar code would treat specially (intersection with an earlier extremal, negative
+  // curve value, loop end) are not eligible and fall to the scalar step. Returns the
+  // number of steps taken (0..64) and advances c.idx / c.cur.
+  template <bool FWD>
+  __device__ __forceinline__ int follow_boundary(Carry &c) {
+    constexpr int dir = FWD ? 1 : -1;
+    const int j = c.idx + dir * lane;            // this lane's step: j -> j + dir
+    const bool in_loop = FWD ? (j < N - 2) : (j > 1);
+    bool elig = false;
+    double m_jn = 0.0, m_j = 0.0;
+    if (in_loop && j >= 0 && j < N) {
+      const int jn = j + dir;
+      m_j = m_g[j];
+      m_jn = m_g[jn];
+      const double nxt = sd2[jn];
+      elig = (typel[j] & kBndTrajectory) && (typel[jn] & kBndTrajectory) &&
+             !(!isnan(nxt) && (nxt < m_jn)) && !(m_jn < 0);
+    }
+    const unsigned long long mask = __ballot(elig);
+    const int L = (~mask == 0ull) ? 64 : (__ffsll((long long)~mask) - 1);
+    if (L == 0) return 0;
+    if (lane < L) {
+      const double cur_k = (lane == 0) ? c.cur : m_j;
+      const double sddv = FWD ? 0.5 * (m_jn - cur_k) / ds : 0.5 * (cur_k - m_jn) / ds;
+      sd2[j + dir] = m_jn;
+      sdd_g[j] = sddv;
+    }
+    wave_lds_sync();
+    c.idx += dir * L;
+    c.cur = readlane_f64(m_jn, L - 1);
+    return L;
+  }
+
+  // (Re)start the carried state at sample idx: tiles, rows, neighbours.
+  template <bool FWD>
+  __device__ __forceinline__ void init_carry(int idx, Carry &c, Rows &rows, Prefetch &pf, bool load_cur) {
+    constexpr int dir = FWD ? 1 : -1;
+    c.idx = idx;
+    ensure_tile(idx, dir, pf);
+    ensure_tile(idx + dir, dir, pf);
+    load_rows(idx, rows);
+    if (load_cur) c.cur = uniform_f64(sd2[idx]);
+    double m0, m1;
+    int t0, t1;
+    load_mt(idx, m0, t0);
+    load_mt(idx + dir, m1, t1);
+    c.m_i = uniform_f64(m0); c.m_n = uniform_f64(m1);
+    c.t_i = uniform_i32(t0); c.t_n = uniform_i32(t1);
+    c.nxt = uniform_f64(sd2[idx + dir]);
+  }
+
   // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952) otherwise.
   // pair_signal (two-wave kernel, backward extremal only): release the partner wave, which
   // runs the forward extremal of the same switching point, once this extremal's FIRST step
   // is complete. Only that step can touch what the partner reads (sd2[icrit-1], sdd[icrit]);
   // afterwards the two extremals work on disjoint index ranges.
-  // The loop is unrolled by two so that the two row sets swap roles without copies.
+  // The scalar loop is unrolled by two so that the two row sets swap roles without copies.
   template <bool FWD>
-  __device__ int add_extremal(int idx_start, bool pair_signal = false) {
+  __device__ __forceinline__ int add_extremal(int idx_start, bool pair_signal = false) {
     constexpr int dir = FWD ? 1 : -1;
+#define TPAMD_PAIR_SIGNAL()                                   \
+  do {                                                        \
+    if (pair_signal) {                                        \
+      __threadfence_block();                                  \
+      __syncthreads();                                        \
+      pair_signal = false;                                    \
+    }                                                         \
+  } while (0)
     if (FWD ? !(idx_start < N - 2) : !(idx_start > 1)) {
-      if (pair_signal) {
-        __threadfence_block();
-        __syncthreads();
-      }
+      TPAMD_PAIR_SIGNAL();
       return FWD ? N - 1 : 0;
     }
     Rows rows_a, rows_b;
     Prefetch pf;
     pf.tag = -1;
     Carry c;
-    c.idx = idx_start;
-    ensure_tile(idx_start, dir, pf);
-    ensure_tile(idx_start + dir, dir, pf);
-    load_rows(idx_start, rows_a);
-    c.cur = uniform_f64(sd2[idx_start]);
-    double m0, m1;
-    int t0, t1;
-    load_mt(idx_start, m0, t0);
-    load_mt(idx_start + dir, m1, t1);
-    c.m_i = uniform_f64(m0); c.m_n = uniform_f64(m1);
-    c.t_i = uniform_i32(t0); c.t_n = uniform_i32(t1);
-    c.nxt = uniform_f64(sd2[idx_start + dir]);
+    init_carry<FWD>(idx_start, c, rows_a, pf, true);
     for (;;) {
+#define TPAMD_TRY_FOLLOW()                                                                   \
+  if (is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {      \
+    const int run = uniform_i32(follow_boundary<FWD>(c));                                    \
+    if (run > 0) {                                                                           \
+      TPAMD_CNT(FWD ? 8 : 9);                                                                \
+      TPAMD_PAIR_SIGNAL();                                                                   \
+      if (FWD ? !(c.idx < N - 2) : !(c.idx > 1)) return FWD ? N - 1 : 0;                     \
+      init_carry<FWD>(c.idx, c, rows_a, pf, false);                                          \
+      continue;                                                                              \
+    }                                                                                        \
+  }
+      TPAMD_TRY_FOLLOW();
       int r = extremal_step<FWD>(c, rows_a, rows_b, pf, idx_start, pair_signal);
       if (r != kContinue) return r;
+      if (is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {
+        // a run starts here: restart the loop (it re-stages into rows_a)
+        load_rows(c.idx, rows_a);
+        continue;
+      }
       r = extremal_step<FWD>(c, rows_b, rows_a, pf, idx_start, pair_signal);
       if (r != kContinue) return r;
     }
+#undef TPAMD_TRY_FOLLOW
+#undef TPAMD_PAIR_SIGNAL
   }
 
   // NextCriticalPoint, .cc:697-720, as two wave-parallel scans over the LDS copies of
@@ -448,7 +520,7 @@ struct JointSweep {
   //  2. first idx >= c0 whose sd2 is already set -> e (none: -1); the answer is the
   //     last idx in (c0, e] with sd2_max[idx] == sd2_max_for_sdd0[0] (sic, index 0,
   //     .cc:710; cached as bit kBndEqualsZ00 of the type byte), else c0.
-  __device__ int next_critical_point(int idx_lo, int idx_hi) const {
+  __device__ __forceinline__ int next_critical_point(int idx_lo, int idx_hi) const {
     int c0 = -1;
     for (int base = idx_lo + 1; base <= idx_hi && c0 < 0; base += 64) {
       const int idx = base + lane;
@@ -520,6 +592,7 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   S.typel = typel;
   int *xchg = reinterpret_cast<int *>(typel + ((N + 15) / 16) * 16);
   S.sdd_g = sdd_out + pb;
+  S.m_g = ws.m + pb;
   S.rec = src.q12 + pb * JS::R;
   S.tag0 = -1; S.tag1 = -1;
   const double *lim_lo = src.lim + (size_t)b * 4 * D, *lim_hi = lim_lo + 2 * D;
