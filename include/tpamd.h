@@ -100,6 +100,10 @@ typedef struct tpamd_joint_inputs {
   const double *sd_start;       /* [B]  SetupProblem sd_start */
   const double *sdd_start;      /* [B]  SetupProblem sdd_start; NULL = 0 */
   const double *time_start;     /* [B]  SetupProblem time_start */
+  /* Ragged batches (BASELINE.json configs[4]): samples of each path, 3 <= n[b] <=
+   * num_samples; NULL = every path has num_samples. All [B][N]-shaped arrays keep the
+   * stride num_samples; entries beyond n[b] are not written. */
+  const int32_t *num_samples_per_path; /* [B] or NULL */
 } tpamd_joint_inputs;
 
 typedef struct tpamd_path_outputs {

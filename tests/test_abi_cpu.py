@@ -35,7 +35,7 @@ def test_header_symbols_are_all_exported(eng):
 def test_struct_layouts_match_header(eng):
     # sizes implied by the C declarations (LP64): 6 int32 + double; 9 / 10 pointers; ...
     assert ctypes.sizeof(eng._JointBatch) == 32
-    assert ctypes.sizeof(eng._JointInputs) == 72
+    assert ctypes.sizeof(eng._JointInputs) == 80
     assert ctypes.sizeof(eng._PathOutputs) == 88
     assert ctypes.sizeof(eng._RowsBatch) == 16
     assert ctypes.sizeof(eng._RowsInputs) == 72

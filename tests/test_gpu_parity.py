@@ -202,6 +202,49 @@ def test_joint_mode_start_velocity_time_offset_and_padding(env):
         np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
 
 
+def _ragged_case(env, D, stride, counts, max_loops=0):
+    """Per-path sample counts (BASELINE.json configs[4]); arrays keep the batch stride."""
+    syn, tpo, torch, eng, E = env["syn"], env["tpo"], env["torch"], env["eng"], env["E"]
+    B = len(counts)
+    b = syn.make_joint_batch(B, D, stride)
+    ns = np.asarray(counts, dtype=np.int32)
+    b["delta"] = b["knots"][:, -1] / np.maximum(ns - 1, 1)
+    inp = eng.upload_joint_batch(b, env["dev"])
+    inp["num_samples_per_path"] = torch.from_numpy(ns).to(env["dev"])
+    out = eng.alloc_joint_outputs(B, stride, D, env["dev"])
+    for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+        out[k].fill_(-7.0)
+    E.time_joint_paths(inp, out, stride, max_solver_loops=max_loops)
+    torch.cuda.synchronize()
+    st = out["status"].cpu().numpy()
+    got = {k: out[k].cpu().numpy() for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd")}
+    nok = 0
+    for i, n in enumerate(counts):
+        one = {k: b[k][i:i + 1] for k in ("knots", "control_points", "vmax", "amax", "path_start",
+                                          "delta", "sd_start", "time_start")}
+        if n < 2 or n > stride:          # n = 1 also has s_start == s_end, which is checked first
+            assert st[i] == (6 if n > stride else 3)
+            continue
+        ref = oracle_joint(env, one, int(n))
+        assert st[i] == ref["status"][0], (i, n)
+        if st[i] != 0:
+            continue
+        nok += 1
+        assert out["last_extremal_index"][i].item() == ref["last_extremal_index"][0]
+        for k in got:
+            np.testing.assert_array_equal(got[k][i, :n], ref["t" if k == "time" else k][0],
+                                          err_msg="%s path %d n %d" % (k, i, n))
+            assert (got[k][i, n:] == -7.0).all(), "wrote past n[b]"     # padding untouched
+    return nok
+
+
+@pytest.mark.parametrize("D", [7, 5])
+def test_ragged_sample_counts_match_oracle_per_path(env, D):
+    rng = np.random.default_rng(5)
+    counts = [600, 3, 64, 65, 33, 1, 601] + list(rng.integers(50, 600, size=25))
+    assert _ragged_case(env, D, 600, counts) >= 20
+
+
 def test_joint_mode_bad_limits_fail_per_path(env):
     syn = env["syn"]
     b = syn.make_joint_batch(6, 7, 300)

@@ -327,8 +327,9 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   int rc = ensure_workspace(e, B, N, C);
   if (rc) return rc;
   e->last_B = B; e->last_N = N;
+  e->ws.ns = in->num_samples_per_path;
   const Workspace &ws = e->ws;
-  const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : std::max(100, 10 * N);
+  const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;  // 0: per path, max(100, 10 n)
   {
     Timer t(e, st, KI_SETUP);
     hipLaunchKernelGGL(k_setup_joint, dim3((B + 127) / 128), dim3(128), 0, st, B, N, D,
@@ -352,8 +353,8 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
     Timer t(e, st, KI_EPILOGUE);
     const size_t total = (size_t)B * N * D;
     hipLaunchKernelGGL(k_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, N,
-                       D, ws.q12, out->sd, out->sdd, in->max_acceleration, out->status, out->qd,
-                       out->qdd);
+                       D, ws.q12, out->sd, out->sdd, in->max_acceleration, out->status, ws.ns,
+                       out->qd, out->qdd);
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -375,6 +376,7 @@ int tpamd_optimize_rows_device(tpamd_engine *e, const tpamd_rows_batch *bt,
   int rc = ensure_workspace(e, B, N, 1);
   if (rc) return rc;
   e->last_B = B; e->last_N = N;
+  e->ws.ns = nullptr;
   const Workspace &ws = e->ws;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 100;
   {
@@ -421,12 +423,14 @@ int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
     int32_t *d_lei = s.take<int32_t>(B), *d_st = s.take<int32_t>(B);
     double *d_dtm = s.take<double>(B);
     double *d_sd2 = out->sd2 ? s.take<double>(B * N) : nullptr;
+    int32_t *d_ns = in->num_samples_per_path ? s.take<int32_t>(B) : nullptr;
     if (!pass) {
       int rc = ensure_stage(e, s.off);
       if (rc) return rc;
       continue;
     }
     hipStream_t st = nullptr;
+    if (d_ns) HIPCHK(hipMemcpyAsync(d_ns, in->num_samples_per_path, B * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_knots, in->knots, B * (P + 3) * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_cp, in->control_points, B * P * D * 8, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d_vmax, in->max_velocity, B * D * 8, hipMemcpyHostToDevice, st));
@@ -439,7 +443,7 @@ int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
     else
       HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
     HIPCHK(hipMemcpyAsync(d_t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
-    tpamd_joint_inputs din{d_knots, d_cp, d_vmax, d_amax, d_ps, d_dl, d_sd0, d_sdd0, d_t0};
+    tpamd_joint_inputs din{d_knots, d_cp, d_vmax, d_amax, d_ps, d_dl, d_sd0, d_sdd0, d_t0, d_ns};
     tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, d_q, d_qd, d_qdd, d_lei, d_dtm, d_st, d_sd2};
     int rc = tpamd_time_joint_paths_device(e, bt, &din, &dout, st);
     if (rc) return rc;

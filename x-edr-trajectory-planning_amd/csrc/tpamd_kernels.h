@@ -22,6 +22,9 @@ struct Workspace {
   // per path
   double *ds, *s_start, *s_end, *sd_start, *sdd_start, *t_start, *delta;
   uint32_t *err_bits;
+  // Ragged batches: number of samples of each path (null: every path has N samples).
+  // Arrays keep the common stride N; only the first ns[b] samples of path b are used.
+  const int32_t *ns;
   double *lim;  // [B][2][C] lower then upper (joint mode)
   // per (path, sample)
   // joint mode: one record of R = 2D+2 doubles per sample,
@@ -39,6 +42,10 @@ struct Workspace {
   long long *diag;  // [B][16] cycle counters; filled only by -DTPAMD_DIAG builds
   double *sd2_out;  // optional caller copy of sd2 ([B][N]); may be null
 };
+
+__device__ __forceinline__ int path_samples(const Workspace &ws, int b, int N) {
+  return ws.ns ? min(ws.ns[b], N) : N;
+}
 
 struct JointSource {
   const double *q12;  // [B][N][2D+2] records
@@ -106,18 +113,19 @@ __global__ void k_setup_joint(int B, int N, int D, double safety, const double *
     if (w > maxw) maxw = w;
     if (lo[c] >= hi[c]) lower_ge_upper = true;
   }
+  const int Nb = path_samples(ws, b, N);
   const double s0 = path_start[b];
-  const double s1 = s0 + delta[b] * (N - 1);
+  const double s1 = s0 + delta[b] * (Nb - 1);
   uint32_t bits = 0;
   if (maxw <= 0) bits |= kErrInfeasible;
   if (s0 >= s1) bits |= kErrSRange;
   if (sd_start[b] < 0) bits |= kErrSdStartNeg;
   if (lower_ge_upper) bits |= kErrLowerGeUpper;
-  if (N < 2) bits |= kErrTooFew;
+  if (Nb < 2 || (ws.ns && ws.ns[b] > N)) bits |= kErrTooFew;   // count outside [2, stride]
   ws.err_bits[b] = bits;
   ws.s_start[b] = s0;
   ws.s_end[b] = s1;
-  ws.ds[b] = (s1 - s0) / (N - 1);
+  ws.ds[b] = (s1 - s0) / (Nb - 1);
   ws.sd_start[b] = sd_start[b];
   ws.sdd_start[b] = sdd_start ? sdd_start[b] : 0.0;
   ws.t_start[b] = t_start[b];
@@ -191,7 +199,7 @@ __global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
   for (int k = tid; k < 2 * C; k += TPB) s_lo[k] = ws.lim[(size_t)b * 2 * C + k];
   __syncthreads();
   const int i = blockIdx.x * TPB + tid;
-  if (i >= N) return;
+  if (i >= path_samples(ws, b, N)) return;
   const size_t o = (size_t)b * N + i;
 
   const double path_start = ws.s_start[b];
@@ -283,7 +291,7 @@ __global__ void k_lp_rows(int N, int C, const double *Ag, const double *Bg, cons
   double *s_A = lds, *s_B = s_A + (size_t)C * TPB, *s_LO = s_B + (size_t)C * TPB,
          *s_HI = s_LO + (size_t)C * TPB;
   const int i0 = blockIdx.x * TPB;
-  const int nvalid = min(TPB, N - i0);
+  const int nvalid = min(TPB, path_samples(ws, b, N) - i0);
   const size_t base = ((size_t)b * N + i0) * C;
   for (int k = tid; k < nvalid * C; k += TPB) {
     const int s = k / C, c = k - s * C;
@@ -340,11 +348,12 @@ __device__ __forceinline__ bool iso_at(const uint8_t *at, int N, int i) {
   return (i >= 1) && (i <= N - 2) && !at[i - 1] && at[i] && !at[i + 1];
 }
 
-__global__ void k_boundary_detect(int N, Workspace ws) {
+__global__ void k_boundary_detect(int stride, Workspace ws) {
   const int b = blockIdx.y;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = path_samples(ws, b, stride);
   if (k >= N) return;
-  const size_t pb = (size_t)b * N;
+  const size_t pb = (size_t)b * stride;
   if (k < 1 || k > N - 2) {
     ws.fix_flag[pb + k] = 0;
     return;
@@ -405,11 +414,12 @@ __device__ __forceinline__ double final_m(const Workspace &ws, size_t pb, int N,
 }
 
 template <class Source>
-__global__ void k_boundary_final(int N, Source src, Workspace ws) {
+__global__ void k_boundary_final(int stride, Source src, Workspace ws) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = path_samples(ws, b, stride);
   if (j >= N) return;
-  const size_t pb = (size_t)b * N;
+  const size_t pb = (size_t)b * stride;
   const uint8_t *ff = ws.fix_flag + pb;
   const uint8_t *at = ws.at0 + pb;
   double m, X, Y;
@@ -420,7 +430,7 @@ __global__ void k_boundary_final(int N, Source src, Workspace ws) {
     m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
   } else if (f_self) {
     m = ws.fix_val[pb + j];
-    const auto r = src.at(b, N, j);
+    const auto r = src.at(b, stride, j);
     if (Source::kJoint) find_sdd_both_joint(r, src.rows() / 2, m, &X, &Y);
     else find_sdd_both(r, src.rows(), m, &X, &Y);
   } else if (iso_at(at, N, j + 1)) {
@@ -448,7 +458,7 @@ __global__ void k_boundary_final(int N, Source src, Workspace ws) {
   // NextCriticalPoint makes against sd2_max_for_sdd0[0] (.cc:710) for the sweep kernel.
   if (m == ws.z0[pb]) type |= kBndEqualsZ00;
   ws.type[pb + j] = type;
-  src.put_record(b, N, j, m, type);
+  src.put_record(b, stride, j, m, type);
 }
 
 // ------------------------------------------------------------- K2: the sweep
@@ -459,7 +469,7 @@ __global__ void k_boundary_final(int N, Source src, Workspace ws) {
 template <class Source>
 struct Sweep {
   Source src;
-  int b, N, C, lane;
+  int b, N, stride, C, lane;   // N samples of this path; arrays use the batch stride
   double ds;
   double *sd2, *sdd;   // LDS [N]
   const double *m;     // final sd2_max [N]
@@ -478,7 +488,7 @@ struct Sweep {
   // candidates are spread over lanes, each lane validates its candidate against
   // all rows, a wave reduction keeps the extreme valid candidate.
   __device__ double find_sdd(int idx, double s2, bool want_max) const {
-    const auto r = src.at(b, N, idx);
+    const auto r = src.at(b, stride, idx);
     double best = want_max ? -DBL_MAX : DBL_MAX;
     for (int c = lane; c < 2 * C; c += 64) {
       const int i = c >> 1;
@@ -502,7 +512,7 @@ struct Sweep {
 
   // AreDerivativesValid (.cc:624-636) with rows spread over lanes.
   __device__ bool derivs_valid(int idx, double sddv, double s2) const {
-    const auto r = src.at(b, N, idx);
+    const auto r = src.at(b, stride, idx);
     bool bad = false;
     for (int i = lane; i < C; i += 64) {
       const double v = r.a(i) * sddv + r.b(i) * s2;
@@ -664,12 +674,12 @@ __device__ __forceinline__ double wave_ordered_prefix(double d, double carry) {
 // 0.5*(sd2[i+-1] - sd2[i]) of a boundary-following step: the division by ds that the
 // reference performs at .cc:787/:877 is done here, off the sequential chain.
 template <class Source>
-__device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N, int lane,
-                           int status, double *sd2, double *sdd, const uint32_t *pend,
+__device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N, int stride,
+                           int lane, int status, double *sd2, double *sdd, const uint32_t *pend,
                            bool copy_sdd, double *t_out, double *s_out, double *sd_out,
                            double *sdd_out, int32_t *lei_out, double *dtmax_out,
                            int32_t *status_out) {
-  const size_t pb = (size_t)b * N;
+  const size_t pb = (size_t)b * stride;
   const double ds = ws.ds[b];
   const double *m = ws.m + pb;
   const int C = src.rows();
@@ -689,7 +699,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
     for (int idx = lane; idx < N; idx += 64) {
       if (isnan(sdd[idx])) {
         // ComputeSddAtIntersection (.cc:722-751) for this sample alone
-        const auto r = src.at(b, N, idx);
+        const auto r = src.at(b, stride, idx);
         const double s2 = sd2[idx];
         const bool has_next = idx < N - 1, has_prev = idx > 0;
         double res = 0.0;
@@ -713,7 +723,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
     // Enforce the start acceleration if admissible (.cc:413-416): rows over lanes.
     {
       const double sdd_start = ws.sdd_start[b];
-      const auto r0 = src.at(b, N, 0);
+      const auto r0 = src.at(b, stride, 0);
       const double s20 = sd2[0];
       bool bad = false;
       for (int i = lane; i < C; i += 64) {
@@ -796,13 +806,14 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
 // Dynamic LDS: sd2[N] | sdd[N] | dt[64]
 template <class Source>
 __global__ void __launch_bounds__(64)
-k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s_out,
+k_sweep(int stride, int max_loops, Source src, Workspace ws, double *t_out, double *s_out,
         double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
         int32_t *status_out) {
   extern __shared__ double lds[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
-  const size_t pb = (size_t)b * N;
+  const int N = path_samples(ws, b, stride);
+  const size_t pb = (size_t)b * stride;
   const uint32_t bits = ws.err_bits[b];
   if (bits) {
     if (lane == 0) {
@@ -813,7 +824,7 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
     return;
   }
   Sweep<Source> S;
-  S.src = src; S.b = b; S.N = N; S.C = src.rows(); S.lane = lane;
+  S.src = src; S.b = b; S.N = N; S.stride = stride; S.C = src.rows(); S.lane = lane;
   S.ds = ws.ds[b];
   S.sd2 = lds; S.sdd = lds + N;
   S.m = ws.m + pb; S.type = ws.type + pb;
@@ -837,6 +848,7 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
   }
   icrit_lo = iforw_hi;
   const double z00 = ws.z0[pb];
+  if (max_loops <= 0) max_loops = max(100, 10 * N);   // path_timing_trajectory.cc:398-400
   for (int loop = 0; loop < max_loops; loop++) {
     if (iforw_hi >= icrit_hi) break;
     icrit = S.next_critical_point(icrit_lo, icrit_hi, z00);
@@ -856,7 +868,7 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
     icrit_lo = iforw_hi;
   }
   __syncthreads();
-  sweep_tail(src, ws, b, N, lane, status, lds, lds + N, nullptr, /*copy_sdd=*/true, t_out, s_out,
+  sweep_tail(src, ws, b, N, stride, lane, status, lds, lds + N, nullptr, /*copy_sdd=*/true, t_out, s_out,
              sd_out, sdd_out, lei_out, dtmax_out, status_out);
 }
 
@@ -865,7 +877,7 @@ k_sweep(int N, int max_loops, Source src, Workspace ws, double *t_out, double *s
 // the (q', q'') pairs and the writes of qd/qdd are contiguous across a wave.
 __global__ void k_epilogue(int B, int N, int D, const double *rec, const double *sd,
                            const double *sdd, const double *amax, const int32_t *status,
-                           double *qd, double *qdd) {
+                           const int32_t *ns, double *qd, double *qdd) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * N * D;
   if (e >= total) return;
@@ -873,6 +885,7 @@ __global__ void k_epilogue(int B, int N, int D, const double *rec, const double 
   const int d = (int)(e - o * D);
   const int b = (int)(o / N);
   if (status[b] != 0) return;
+  if (ns && (int)(o - (size_t)b * N) >= ns[b]) return;
   const double v = sd[o], a = sdd[o];
   const double v2 = v * v;
   const double2 pr = *reinterpret_cast<const double2 *>(rec + o * (2 * D + 2) + 2 * d);

@@ -563,7 +563,7 @@ __host__ __device__ inline size_t sweep_joint_lds_bytes(int N, int waves) {
 // first step, see add_extremal). Both waves keep identical copies of the loop scalars.
 template <int D, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
-k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
+k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
               double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
               int32_t *status_out) {
   extern __shared__ double lds[];
@@ -571,7 +571,8 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   const int lane = threadIdx.x & 63;
   const int w = (WAVES == 2) ? uniform_i32((int)(threadIdx.x >> 6)) : 0;
   const int tid = threadIdx.x;
-  const size_t pb = (size_t)b * N;
+  const int N = path_samples(ws, b, stride);   // samples of this path; arrays use `stride`
+  const size_t pb = (size_t)b * stride;
   const uint32_t bits = ws.err_bits[b];
   if (bits) {
     if (tid == 0) {
@@ -667,6 +668,7 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   }
   icrit_lo = iforw_hi;
   const double *m_g = ws.m + pb;
+  if (max_loops <= 0) max_loops = max(100, 10 * N);   // path_timing_trajectory.cc:398-400
   for (int loop = 0; loop < max_loops; loop++) {
     if (iforw_hi >= icrit_hi) break;
     if (WAVES == 2) __syncthreads();   // sd2 writes of the other wave / the NaN mark are visible
@@ -731,7 +733,7 @@ k_sweep_joint(int N, int max_loops, JointSource src, Workspace ws, double *t_out
   if (w != 0) return;
   {
     TPAMD_T0(t0);
-    sweep_tail(src, ws, b, N, lane, status, sd2, S.sdd_g, nullptr, /*copy_sdd=*/false, t_out, s_out,
+    sweep_tail(src, ws, b, N, stride, lane, status, sd2, S.sdd_g, nullptr, /*copy_sdd=*/false, t_out, s_out,
                sd_out, sdd_out, lei_out, dtmax_out, status_out);
     TPAMD_ACC(3, t0);
   }

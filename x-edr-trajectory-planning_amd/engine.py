@@ -59,7 +59,7 @@ class _JointBatch(C.Structure):
 class _JointInputs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "knots", "control_points", "max_velocity", "max_acceleration", "path_start", "delta",
-        "sd_start", "sdd_start", "time_start")]
+        "sd_start", "sdd_start", "time_start", "num_samples_per_path")]
 
 
 class _PathOutputs(C.Structure):
@@ -220,7 +220,7 @@ class Engine:
         bt = _JointBatch(B, D, int(num_samples), P, int(max_solver_loops), 0, float(safety))
         ji = _JointInputs(*[_ptr(inputs.get(k)) for k in (
             "knots", "control_points", "max_velocity", "max_acceleration", "path_start", "delta",
-            "sd_start", "sdd_start", "time_start")])
+            "sd_start", "sdd_start", "time_start", "num_samples_per_path")])
         po = _PathOutputs(*[_ptr(outputs.get(k)) for k in (
             "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
             "max_time_increment", "status", "sd2")])
