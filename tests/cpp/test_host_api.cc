@@ -246,10 +246,67 @@ static void TestBatch() {
   }
 }
 
+// BASELINE.json configs[4] in miniature: 6/7/14 DOF, different sample and waypoint counts in one
+// SetPaths call; every path must equal its own single-path oracle run bit for bit.
+static void TestMixedBatch() {
+  const int B = 30;
+  const int dofs[3] = {6, 7, 14};
+  std::vector<std::shared_ptr<TimeableJointSplinePath>> paths;
+  unsigned long long seed = 777;
+  auto rnd = [&]() { seed = seed * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(seed >> 11) / 9007199254740992.0; };
+  std::vector<double> deltas(B);
+  std::vector<int> Ns(B), Ws(B), Ds(B);
+  for (int b = 0; b < B; b++) {
+    Ds[b] = dofs[b % 3];
+    Ns[b] = 100 + (int)(rnd() * 500);
+    Ws[b] = (b % 5 == 0) ? 4 : 6;
+    std::vector<VectorXd> wps;
+    for (int i = 0; i < Ws[b]; i++) {
+      VectorXd v(Ds[b]);
+      for (int d = 0; d < Ds[b]; d++) v[d] = 4.0 * rnd() - 2.0;
+      wps.push_back(v);
+    }
+    paths.push_back(MakePath(Ns[b], wps, 1.0 + rnd(), 2.0 + 2.0 * rnd(), &deltas[b]));
+  }
+  BatchPathTiming batch;
+  CHECK(batch.SetPaths(paths).ok());
+  BatchTimingResult r;
+  CHECK(batch.ComputeTimingProfiles(0.25, &r).ok());
+  CHECK(r.num_dofs == 14);
+  for (int b = 0; b < B; b++) {
+    const int N = Ns[b], D = Ds[b], P = 3 * Ws[b] - 2;
+    CHECK(r.samples_per_path[b] == N && r.dofs_per_path[b] == D);
+    CHECK(r.sample_offset[b + 1] - r.sample_offset[b] == (size_t)N);
+    std::vector<double> t(N), s(N), sd(N), sdd(N), q(N * D), qd(N * D), qdd(N * D);
+    int lei = 0;
+    const int rc = tpo_time_joint_path(paths[b]->knots().data(), P + 3, paths[b]->packed_control_points().data(),
+                                       P, D, paths[b]->GetMaxJointVelocity().data(),
+                                       paths[b]->GetMaxJointAcceleration().data(), 0.8, 0.0, deltas[b], N,
+                                       0.0, 0.0, 0.25, nullptr, t.data(), s.data(), sd.data(), sdd.data(),
+                                       q.data(), qd.data(), qdd.data(), &lei);
+    CHECK(rc == r.status[b]);
+    if (rc != 0) continue;
+    CHECK(lei == r.last_extremal_index[b]);
+    const size_t so = r.sample_offset[b], jo = r.joint_offset[b];
+    for (int i = 0; i < N; i++) {
+      CHECK(r.time[so + i] == t[i]);
+      CHECK(r.s[so + i] == s[i]);
+      CHECK(r.sd[so + i] == sd[i]);
+      CHECK(r.sdd[so + i] == sdd[i]);
+    }
+    for (int i = 0; i < N * D; i++) {
+      CHECK(r.q[jo + i] == q[i]);
+      CHECK(r.qd[jo + i] == qd[i]);
+      CHECK(r.qdd[jo + i] == qdd[i]);
+    }
+  }
+}
+
 int main() {
   TestProfileAgainstOracle();
   TestJointPathAndPlanner();
   TestBatch();
+  TestMixedBatch();
   if (g_fail == 0) std::printf("ALL OK\n");
   else std::printf("%d CHECKS FAILED\n", g_fail);
   return g_fail == 0 ? 0 : 1;

@@ -188,7 +188,7 @@ Status PathTimingTrajectory::ComputeTimingProfile(Time start, Duration target_du
     tpamd_joint_inputs in{joint->knots().data(), joint->packed_control_points().data(),
                           joint->GetMaxJointVelocity().data(), joint->GetMaxJointAcceleration().data(),
                           &path_start_, &delta, &path_start_velocity_, &path_start_acceleration_,
-                          &path_time_start_};
+                          &path_time_start_, nullptr};
     std::vector<double> t(N), s(N), sd(N), sdd(N), sd2(N);
     int32_t lei = 0, status = -1;
     double dtmax = 0;
