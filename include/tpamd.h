@@ -165,6 +165,42 @@ int tpamd_optimize_rows_host(tpamd_engine *engine, const tpamd_rows_batch *batch
                              const tpamd_rows_inputs *in,
                              const tpamd_path_outputs *out);
 
+/* ------------------------------------------------------------------------
+ * Form (iii): Cartesian-space paths after the IK callback (BASELINE.json configs[3]).
+ * Replaces, for B paths at once, the arithmetic of TimeableCartesianSplinePath that
+ * follows path_ik_func_: ComputePathDerivatives (timeable_path_cartesian_spline.cc:39-68,
+ * called from SamplePath :541-542), ConstraintSetup (:551-595, C = 2D+2 rows), then
+ * the solver and the planner epilogue as for joint paths. The pose-spline sampling, the
+ * IK callback and the Jacobian callback are user std::functions (:508-510, :576) and stay
+ * on the host: their results are the inputs here. J*q' is summed over the dofs in index
+ * order. max_solver_loops <= 0: max(100, 10 N).
+ * ------------------------------------------------------------------------ */
+typedef struct tpamd_cartesian_batch {
+  int32_t num_paths;        /* B */
+  int32_t num_dofs;         /* D, 1..16 */
+  int32_t num_samples;      /* N */
+  int32_t max_solver_loops;
+  double constraint_safety; /* CartesianPathOptions::constraint_safety */
+} tpamd_cartesian_batch;
+
+typedef struct tpamd_cartesian_inputs {
+  const double *ik_positions;  /* [B][N][D]    path_position_ (IK solution per sample) */
+  const double *jacobians;     /* [B][N][6][D] jacobian_func_(path_position_[i]), row-major */
+  const double *max_velocity;      /* [B][D] */
+  const double *max_acceleration;  /* [B][D] */
+  const double *max_translational_velocity; /* [B] */
+  const double *max_rotational_velocity;    /* [B] */
+  const double *path_start, *delta, *sd_start, *sdd_start, *time_start; /* [B] each; sdd_start may be NULL */
+} tpamd_cartesian_inputs;
+
+/* out->q, if given, receives a copy of ik_positions. */
+int tpamd_time_cartesian_paths_device(tpamd_engine *engine, const tpamd_cartesian_batch *batch,
+                                      const tpamd_cartesian_inputs *in,
+                                      const tpamd_path_outputs *out, void *hip_stream);
+int tpamd_time_cartesian_paths_host(tpamd_engine *engine, const tpamd_cartesian_batch *batch,
+                                    const tpamd_cartesian_inputs *in,
+                                    const tpamd_path_outputs *out);
+
 /* Batched TimeOptimalPathProfile::FindMaxSd2Simplex (time_optimal_path_timing.cc:1149-1363)
  * on num_lps independent constraint sets of C rows each ([num_lps][C] arrays);
  * outputs sd2max/sddmax/sd2zero [num_lps]. Host pointers. */

@@ -1228,3 +1228,79 @@ int tpo_time_joint_batch(int B, const double *knots, int num_knots,
   }
   return failed;
 }
+
+/* jacobian * first_path_derivative (timeable_path_cartesian_spline.cc:577): J is
+ * [N][6][D] row-major, the product is accumulated over the dofs in index order.
+ * Eigen's own summation order for this 6xD product is an implementation detail
+ * (it may differ in the last ulp); parity on these two rows is 1e-6 relative. */
+void tpo_cartesian_jacobian_times_q1(const double *J, const double *q1, int N, int D,
+                                     double *jq1) {
+  for (int i = 0; i < N; i++)
+    for (int r = 0; r < 6; r++) {
+      double acc = 0.0;
+      for (int d = 0; d < D; d++) acc += J[((size_t)i * 6 + r) * D + d] * q1[(size_t)i * D + d];
+      jq1[(size_t)i * 6 + r] = acc;
+    }
+}
+
+/* The Cartesian path's share of ComputeTimingProfile after the IK callback has run:
+ * ComputePathDerivatives (:39-68, called from SamplePath :541-542), ConstraintSetup
+ * (:551-595), then the solver and the planner epilogue exactly as for a joint path
+ * (path_timing_trajectory.cc:340-341, :398-400, :458-472). */
+int tpo_time_cartesian_path(const double *q, const double *J, int N, int D,
+                            const double *vmax, const double *amax, double max_trans_vel,
+                            double max_rot_vel, double safety, double path_start,
+                            double delta, double sd_start, double sdd_start,
+                            double time_start, double *t, double *s, double *sd,
+                            double *sdd, double *qd, double *qdd,
+                            int *last_extremal_index) {
+  const int C = 2 * D + 2;
+  tpo_profile *p = tpo_profile_create(N, C);
+  double *q1 = (double *)malloc(sizeof(double) * (2 * (size_t)N * D + 6 * (size_t)N));
+  double *q2 = q1 + (size_t)N * D, *jq1 = q2 + (size_t)N * D;
+  double *rows = (double *)malloc(sizeof(double) * 4 * (size_t)N * C);
+  double *A = rows, *B = rows + (size_t)N * C, *lo = B + (size_t)N * C, *hi = lo + (size_t)N * C;
+  tpo_cartesian_path_derivatives(q, N, D, delta, q1, q2);
+  tpo_cartesian_jacobian_times_q1(J, q1, N, D, jq1);
+  tpo_cartesian_constraint_setup(q1, q2, jq1, N, D, vmax, amax, max_trans_vel, max_rot_vel,
+                                 safety, A, B, lo, hi);
+  tpo_profile_set_max_loops(p, (100 > 10 * N) ? 100 : 10 * N);
+  int rc = tpo_profile_setup(p, A, B, lo, hi, path_start, path_start + delta * (N - 1),
+                             sd_start, sdd_start, time_start);
+  if (rc == TPO_OK) rc = tpo_profile_optimize(p);
+  if (rc == TPO_OK) {
+    memcpy(t, p->time, sizeof(double) * N);
+    memcpy(s, p->s, sizeof(double) * N);
+    memcpy(sd, p->sd, sizeof(double) * N);
+    memcpy(sdd, p->sdd, sizeof(double) * N);
+    tpo_epilogue(q1, q2, N, D, p->sd, p->sdd, amax, qd, qdd);
+    if (last_extremal_index) *last_extremal_index = p->last_extremal_index;
+  }
+  free(q1); free(rows);
+  tpo_profile_destroy(p);
+  return rc;
+}
+
+int tpo_time_cartesian_batch(int B, const double *q, const double *J, int N, int D,
+                             const double *vmax, const double *amax,
+                             const double *max_trans_vel, const double *max_rot_vel,
+                             double safety, const double *path_start, const double *delta,
+                             const double *sd_start, const double *time_start, int nthreads,
+                             double *t, double *s, double *sd, double *sdd, double *qd,
+                             double *qdd, int *last_extremal_index, int *status) {
+  int failed = 0;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4) reduction(+ : failed)
+  for (int b = 0; b < B; b++) {
+    int lei = 0;
+    const int rc = tpo_time_cartesian_path(
+        q + (size_t)b * N * D, J + (size_t)b * N * 6 * D, N, D, vmax + (size_t)b * D,
+        amax + (size_t)b * D, max_trans_vel[b], max_rot_vel[b], safety, path_start[b], delta[b],
+        sd_start[b], 0.0, time_start[b], t + (size_t)b * N, s + (size_t)b * N, sd + (size_t)b * N,
+        sdd + (size_t)b * N, qd + (size_t)b * N * D, qdd + (size_t)b * N * D, &lei);
+    status[b] = rc;
+    if (last_extremal_index) last_extremal_index[b] = lei;
+    if (rc != TPO_OK) failed++;
+  }
+  return failed;
+}

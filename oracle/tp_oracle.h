@@ -215,6 +215,24 @@ int tpo_time_joint_batch(int B, const double *knots, int num_knots,
                          double *sdd, double *q, double *qd, double *qdd,
                          int *last_extremal_index, int *status);
 
+/* Cartesian path after the IK callback (see tp_oracle.c): q [N][D], J [N][6][D]. */
+void tpo_cartesian_jacobian_times_q1(const double *J, const double *q1, int N, int D,
+                                     double *jq1);
+int tpo_time_cartesian_path(const double *q, const double *J, int N, int D,
+                            const double *vmax, const double *amax, double max_trans_vel,
+                            double max_rot_vel, double safety, double path_start,
+                            double delta, double sd_start, double sdd_start,
+                            double time_start, double *t, double *s, double *sd,
+                            double *sdd, double *qd, double *qdd,
+                            int *last_extremal_index);
+int tpo_time_cartesian_batch(int B, const double *q, const double *J, int N, int D,
+                             const double *vmax, const double *amax,
+                             const double *max_trans_vel, const double *max_rot_vel,
+                             double safety, const double *path_start, const double *delta,
+                             const double *sd_start, const double *time_start, int nthreads,
+                             double *t, double *s, double *sd, double *sdd, double *qd,
+                             double *qdd, int *last_extremal_index, int *status);
+
 #ifdef __cplusplus
 }
 #endif

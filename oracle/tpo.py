@@ -111,6 +111,9 @@ def lib():
     L.tpo_time_joint_batch.restype = i
     L.tpo_time_joint_batch.argtypes = [i, _dp, i, _dp, i, i, _dp, _dp, d, _dp, _dp, i, _dp, _dp,
                                        i, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
+    L.tpo_time_cartesian_batch.restype = i
+    L.tpo_time_cartesian_batch.argtypes = [i, _dp, _dp, i, i, _dp, _dp, _dp, _dp, d, _dp, _dp, _dp,
+                                           _dp, i, _dp, _dp, _dp, _dp, _dp, _dp, _ip, _ip]
     _LIB = L
     return L
 
@@ -348,3 +351,23 @@ def time_joint_batch(knots, cps, vmax, amax, path_start, delta, N, sd_start=None
                                t, s, sd, sdd, q, qd, qdd, lei, status)
     return dict(t=t, s=s, sd=sd, sdd=sdd, q=q, qd=qd, qdd=qdd,
                 last_extremal_index=lei, status=status)
+
+
+def time_cartesian_batch(q, J, vmax, amax, vtrans, vrot, path_start, delta, sd_start=None,
+                         time_start=None, safety=0.8, nthreads=1):
+    """IK positions q [B][N][D], Jacobians J [B][N][6][D] -> timing as time_joint_batch."""
+    q, J = _f64(q), _f64(J)
+    B, N, D = q.shape
+    assert J.shape == (B, N, 6, D)
+    bc = lambda v: _f64(np.broadcast_to(v, (B,)))
+    sd_start = bc(0.0 if sd_start is None else sd_start)
+    time_start = bc(0.0 if time_start is None else time_start)
+    t, s, sd, sdd = (np.zeros((B, N)) for _ in range(4))
+    qd, qdd = (np.zeros((B, N, D)) for _ in range(2))
+    lei = np.zeros(B, dtype=np.int32)
+    status = np.zeros(B, dtype=np.int32)
+    lib().tpo_time_cartesian_batch(B, q, J, N, D, _f64(vmax), _f64(amax), bc(vtrans), bc(vrot),
+                                   float(safety), bc(path_start), bc(delta), sd_start, time_start,
+                                   int(nthreads), t, s, sd, sdd, qd, qdd, lei, status)
+    return dict(t=t, s=s, sd=sd, sdd=sdd, q=q, qd=qd, qdd=qdd, last_extremal_index=lei,
+                status=status)

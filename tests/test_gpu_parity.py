@@ -245,6 +245,52 @@ def test_ragged_sample_counts_match_oracle_per_path(env, D):
     assert _ragged_case(env, D, 600, counts) >= 20
 
 
+# ------------------------------------------ Cartesian paths (BASELINE.json configs[3])
+@pytest.mark.parametrize("D,N,B", [(6, 800, 24), (7, 500, 8), (6, 2000, 8), (3, 64, 3)])
+def test_cartesian_paths_match_oracle(env, D, N, B):
+    syn, tpo, torch, eng, E = env["syn"], env["tpo"], env["torch"], env["eng"], env["E"]
+    b = syn.make_cartesian_batch(B, D, N)
+    b["time_start"] = np.linspace(0.0, 3.0, B)
+    b["vtrans"][0] = 0.0          # degenerate Cartesian row (lower == upper): fails that path only
+    ref = tpo.time_cartesian_batch(b["ik_positions"], b["jacobians"], b["vmax"], b["amax"],
+                                   b["vtrans"], b["vrot"], b["path_start"], b["delta"],
+                                   time_start=b["time_start"], nthreads=8)
+    inp = syn.upload_cartesian_batch(b, env["dev"])
+    out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    E.time_cartesian_paths(inp, out)
+    torch.cuda.synchronize()
+    st = out["status"].cpu().numpy()
+    np.testing.assert_array_equal(st, ref["status"])
+    assert st[0] == 5
+    ok = st == 0
+    assert ok.sum() >= B - 2
+    np.testing.assert_array_equal(out["last_extremal_index"].cpu().numpy()[ok],
+                                  ref["last_extremal_index"][ok])
+    for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+        np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok],
+                                      err_msg=k)
+    # Cartesian rows are respected: |J q'|^2 sd^2 <= v^2 (+ solver tolerance)
+    q = b["ik_positions"]
+    q1 = np.zeros_like(q)
+    q1[:, :-1] = (q[:, 1:] - q[:, :-1]) / b["delta"][:, None, None]
+    v6 = np.einsum("bnrd,bnd->bnr", b["jacobians"], q1)
+    sd2 = out["sd"].cpu().numpy() ** 2
+    assert (((v6[..., :3] ** 2).sum(-1) * sd2)[ok] <= (b["vtrans"][ok, None] ** 2) * (1 + 1e-6) + 1e-9).all()
+    assert (((v6[..., 3:] ** 2).sum(-1) * sd2)[ok] <= (b["vrot"][ok, None] ** 2) * (1 + 1e-6) + 1e-9).all()
+    # host-buffer entry point returns the same bits
+    hin = dict(ik_positions=b["ik_positions"], jacobians=b["jacobians"], max_velocity=b["vmax"],
+               max_acceleration=b["amax"], max_translational_velocity=b["vtrans"],
+               max_rotational_velocity=b["vrot"], path_start=b["path_start"], delta=b["delta"],
+               sd_start=b["sd_start"], time_start=b["time_start"])
+    hout = dict(time=np.zeros((B, N)), s=np.zeros((B, N)), sd=np.zeros((B, N)),
+                sdd=np.zeros((B, N)), qd=np.zeros((B, N, D)), qdd=np.zeros((B, N, D)),
+                status=np.full(B, -1, np.int32))
+    E.time_cartesian_paths(hin, hout, host=True)
+    np.testing.assert_array_equal(hout["status"], st)
+    for k in ("time", "sd", "qdd"):
+        np.testing.assert_array_equal(hout[k][ok], out[k].cpu().numpy()[ok])
+
+
 def test_joint_mode_bad_limits_fail_per_path(env):
     syn = env["syn"]
     b = syn.make_joint_batch(6, 7, 300)

@@ -60,6 +60,8 @@ struct tpamd_engine {
   size_t ws_bytes = 0;
   void *stage_base = nullptr;  // staging for the _host entry points
   size_t stage_bytes = 0;
+  void *rows_base = nullptr;   // assembled constraint rows of Cartesian batches
+  size_t rows_bytes = 0;
   Workspace ws{};
   int last_B = 0, last_N = 0;
   bool profile = false;
@@ -128,6 +130,17 @@ int ensure_stage(tpamd_engine *e, size_t need) {
     e->stage_bytes = 0;
     HIPCHK(hipMalloc(&e->stage_base, need));
     e->stage_bytes = need;
+  }
+  return 0;
+}
+
+int ensure_rows(tpamd_engine *e, size_t need) {
+  if (need > e->rows_bytes) {
+    if (e->rows_base) HIPCHK(hipFree(e->rows_base));
+    e->rows_base = nullptr;
+    e->rows_bytes = 0;
+    HIPCHK(hipMalloc(&e->rows_base, need));
+    e->rows_bytes = need;
   }
   return 0;
 }
@@ -245,6 +258,26 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
   return 0;
 }
 
+// LP boundary points of explicit rows, then the shared tail.
+int run_rows(tpamd_engine *e, hipStream_t st, int B, int N, int C, int max_loops, const double *a,
+             const double *b, const double *lower, const double *upper,
+             const tpamd_path_outputs *out) {
+  const Workspace &ws = e->ws;
+  {
+    Timer t(e, st, KI_SAMPLE_LP);
+    const int tpb = 64;
+    const size_t lds = 4 * (size_t)C * tpb * 8;
+    const dim3 grid((N + tpb - 1) / tpb, B);
+    if (C <= 32)
+      hipLaunchKernelGGL((k_lp_rows<1>), grid, dim3(tpb), lds, st, N, C, a, b, lower, upper, ws);
+    else
+      hipLaunchKernelGGL((k_lp_rows<2>), grid, dim3(tpb), lds, st, N, C, a, b, lower, upper, ws);
+  }
+  GenericSource src;
+  src.A = a; src.B = b; src.LO = lower; src.HI = upper; src.C = C;
+  return run_boundary_and_sweep(e, st, B, N, max_loops, src, out);
+}
+
 }  // namespace
 
 extern "C" {
@@ -299,6 +332,7 @@ void tpamd_engine_destroy(tpamd_engine *e) {
   for (auto &ev : e->events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
   if (e->ws_base) (void)hipFree(e->ws_base);
   if (e->stage_base) (void)hipFree(e->stage_base);
+  if (e->rows_base) (void)hipFree(e->rows_base);
   delete e;
 }
 
@@ -384,21 +418,127 @@ int tpamd_optimize_rows_device(tpamd_engine *e, const tpamd_rows_batch *bt,
     hipLaunchKernelGGL(k_setup_rows, dim3((B + 127) / 128), dim3(128), 0, st, B, N, in->s_start,
                        in->s_end, in->sd_start, in->sdd_start, in->time_start, ws);
   }
+  return run_rows(e, st, B, N, C, max_loops, in->a, in->b, in->lower, in->upper, out);
+}
+
+int tpamd_time_cartesian_paths_device(tpamd_engine *e, const tpamd_cartesian_batch *bt,
+                                      const tpamd_cartesian_inputs *in,
+                                      const tpamd_path_outputs *out, void *hip_stream) {
+  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+  const int B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples;
+  if (B <= 0) return B == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (D < 1 || D > 16 || N < 3 || N > 8192) return TPAMD_E_UNSUPPORTED;
+  if (!in->ik_positions || !in->jacobians || !in->max_velocity || !in->max_acceleration ||
+      !in->max_translational_velocity || !in->max_rotational_velocity || !in->path_start ||
+      !in->delta || !in->sd_start || !in->time_start || !out->time || !out->s || !out->sd ||
+      !out->sdd || !out->status)
+    return TPAMD_E_INVALID_ARGUMENT;
+  HIPCHK(hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const int C = 2 * D + 2;
+  int rc = ensure_workspace(e, B, N, 2 * D);
+  if (rc) return rc;
+  const size_t nrow = align_up((size_t)B * N * C * 8, 256);
+  rc = ensure_rows(e, 4 * nrow);
+  if (rc) return rc;
+  e->last_B = B; e->last_N = N;
+  e->ws.ns = nullptr;
+  const Workspace &ws = e->ws;
+  double *A = (double *)e->rows_base, *Bm = (double *)((char *)e->rows_base + nrow),
+         *LO = (double *)((char *)e->rows_base + 2 * nrow),
+         *HI = (double *)((char *)e->rows_base + 3 * nrow);
+  const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;
   {
-    Timer t(e, st, KI_SAMPLE_LP);
-    const int tpb = 64;
-    const size_t lds = 4 * (size_t)C * tpb * 8;
-    const dim3 grid((N + tpb - 1) / tpb, B);
-    if (C <= 32)
-      hipLaunchKernelGGL((k_lp_rows<1>), grid, dim3(tpb), lds, st, N, C, in->a, in->b, in->lower,
-                         in->upper, ws);
-    else
-      hipLaunchKernelGGL((k_lp_rows<2>), grid, dim3(tpb), lds, st, N, C, in->a, in->b, in->lower,
-                         in->upper, ws);
+    Timer t(e, st, KI_SETUP);
+    hipLaunchKernelGGL(k_setup_cartesian, dim3((B + 127) / 128), dim3(128), 0, st, B, N,
+                       in->path_start, in->delta, in->sd_start, in->sdd_start, in->time_start, ws);
+    hipLaunchKernelGGL(k_cartesian_rows, dim3((N + 127) / 128, B), dim3(128), 0, st, N, D,
+                       bt->constraint_safety, in->ik_positions, in->jacobians, in->max_velocity,
+                       in->max_acceleration, in->max_translational_velocity,
+                       in->max_rotational_velocity, A, Bm, LO, HI, ws);
   }
-  GenericSource src;
-  src.A = in->a; src.B = in->b; src.LO = in->lower; src.HI = in->upper; src.C = C;
-  return run_boundary_and_sweep(e, st, B, N, max_loops, src, out);
+  rc = run_rows(e, st, B, N, C, max_loops, A, Bm, LO, HI, out);
+  if (rc) return rc;
+  if (out->q)
+    HIPCHK(hipMemcpyAsync(out->q, in->ik_positions, (size_t)B * N * D * 8,
+                          hipMemcpyDeviceToDevice, st));
+  if (out->qd || out->qdd) {
+    Timer t(e, st, KI_EPILOGUE);
+    const size_t total = (size_t)B * N * D;
+    hipLaunchKernelGGL(k_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, N,
+                       D, ws.q12, out->sd, out->sdd, in->max_acceleration, out->status, ws.ns,
+                       out->qd, out->qdd);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tpamd_time_cartesian_paths_host(tpamd_engine *e, const tpamd_cartesian_batch *bt,
+                                    const tpamd_cartesian_inputs *in,
+                                    const tpamd_path_outputs *out) {
+  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+  if (bt->num_paths <= 0) return bt->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (!in->ik_positions || !in->jacobians || !in->max_velocity || !in->max_acceleration ||
+      !in->max_translational_velocity || !in->max_rotational_velocity || !in->path_start ||
+      !in->delta || !in->sd_start || !in->time_start || !out->time || !out->s || !out->sd ||
+      !out->sdd || !out->status)
+    return TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples;
+  HIPCHK(hipSetDevice(e->device));
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_q = s.take<double>(B * N * D), *d_J = s.take<double>(B * N * 6 * D);
+    double *d_vmax = s.take<double>(B * D), *d_amax = s.take<double>(B * D);
+    double *d_vt = s.take<double>(B), *d_vr = s.take<double>(B);
+    double *d_ps = s.take<double>(B), *d_dl = s.take<double>(B), *d_sd0 = s.take<double>(B);
+    double *d_sdd0 = s.take<double>(B), *d_t0 = s.take<double>(B);
+    double *d_t = s.take<double>(B * N), *d_s = s.take<double>(B * N);
+    double *d_sd = s.take<double>(B * N), *d_sdd = s.take<double>(B * N);
+    double *d_qd = out->qd ? s.take<double>(B * N * D) : nullptr;
+    double *d_qdd = out->qdd ? s.take<double>(B * N * D) : nullptr;
+    int32_t *d_lei = s.take<int32_t>(B), *d_st = s.take<int32_t>(B);
+    double *d_dtm = s.take<double>(B);
+    double *d_sd2 = out->sd2 ? s.take<double>(B * N) : nullptr;
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(d_q, in->ik_positions, B * N * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_J, in->jacobians, B * N * 6 * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_vmax, in->max_velocity, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_amax, in->max_acceleration, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_vt, in->max_translational_velocity, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_vr, in->max_rotational_velocity, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ps, in->path_start, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_dl, in->delta, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_sd0, in->sd_start, B * 8, hipMemcpyHostToDevice, st));
+    if (in->sdd_start)
+      HIPCHK(hipMemcpyAsync(d_sdd0, in->sdd_start, B * 8, hipMemcpyHostToDevice, st));
+    else
+      HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
+    HIPCHK(hipMemcpyAsync(d_t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
+    tpamd_cartesian_inputs din{d_q, d_J, d_vmax, d_amax, d_vt, d_vr, d_ps, d_dl, d_sd0, d_sdd0, d_t0};
+    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, nullptr, d_qd, d_qdd, d_lei, d_dtm, d_st, d_sd2};
+    int rc = tpamd_time_cartesian_paths_device(e, bt, &din, &dout, st);
+    if (rc) return rc;
+    if (out->sd2) HIPCHK(hipMemcpyAsync(out->sd2, d_sd2, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->time, d_t, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->s, d_s, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->sd, d_sd, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->sdd, d_sdd, B * N * 8, hipMemcpyDeviceToHost, st));
+    if (out->qd) HIPCHK(hipMemcpyAsync(out->qd, d_qd, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    if (out->qdd) HIPCHK(hipMemcpyAsync(out->qdd, d_qdd, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    if (out->last_extremal_index)
+      HIPCHK(hipMemcpyAsync(out->last_extremal_index, d_lei, B * 4, hipMemcpyDeviceToHost, st));
+    if (out->max_time_increment)
+      HIPCHK(hipMemcpyAsync(out->max_time_increment, d_dtm, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(out->status, d_st, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (out->q && out->q != in->ik_positions) std::memcpy(out->q, in->ik_positions, B * N * D * 8);
+  }
+  return 0;
 }
 
 // ---- host-buffer convenience paths ---------------------------------------

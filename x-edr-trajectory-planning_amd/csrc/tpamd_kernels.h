@@ -279,6 +279,81 @@ __global__ void k_sample_only(int N, int D, int P, const double *knots_g, const 
   }
 }
 
+// ------------------------------------------- Cartesian paths: rows from IK output
+// One thread per (path, sample). ComputePathDerivatives
+// (timeable_path_cartesian_spline.cc:39-68): forward differences of the IK positions,
+// q'[N-1] = 0, q''[0] = q''[N-1] = 0. ConstraintSetup (:551-595): the 2D joint rows plus
+// two rows bounding |(J q')_{1..3}|^2 and |(J q')_{4..6}|^2 with lower = -upper. The
+// Jacobians [B][N][6][D] are evaluated by the caller's jacobian_func_ (:576); J q' is
+// accumulated over the dofs in index order. Rows go to A/Bm/LO/HI [B][N][2D+2]; the
+// (q', q'') pairs go to the sample's record for k_epilogue.
+__global__ void k_cartesian_rows(int N, int D, double safety, const double *q_g,
+                                 const double *J_g, const double *vmax, const double *amax,
+                                 const double *vtrans, const double *vrot, double *A,
+                                 double *Bm, double *LO, double *HI, Workspace ws) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int C = 2 * D + 2;
+  const size_t o = (size_t)b * N + i;
+  const double inv = 1.0 / ws.delta[b];
+  const double *q = q_g + o * D;
+  const double *J = J_g + o * 6 * D;
+  double *rec = ws.q12 + o * (2 * D + 2);
+  double *a = A + o * C, *bb = Bm + o * C, *lo = LO + o * C, *hi = HI + o * C;
+  double v6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int d = 0; d < D; d++) {
+    double q1 = 0.0, q2 = 0.0;
+    if (i < N - 1) {
+      q1 = inv * (q[D + d] - q[d]);
+      if (i >= 1) {
+        const double q1n = (i + 1 < N - 1) ? inv * (q[2 * D + d] - q[D + d]) : 0.0;
+        q2 = inv * (q1n - q1);
+      }
+    }
+    rec[2 * d] = q1;
+    rec[2 * d + 1] = q2;
+    const double am = amax[(size_t)b * D + d] * safety;
+    const double vm = vmax[(size_t)b * D + d] * safety;
+    a[d] = q1;       bb[d] = q2;          hi[d] = am;          lo[d] = -am;
+    a[D + d] = 0.0;  bb[D + d] = q1 * q1; hi[D + d] = vm * vm; lo[D + d] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; r++) v6[r] += J[r * D + d] * q1;
+  }
+  const double vt = vtrans[b], vr = vrot[b];
+  a[2 * D] = 0.0;
+  bb[2 * D] = (v6[0] * v6[0] + v6[1] * v6[1]) + v6[2] * v6[2];
+  hi[2 * D] = vt * vt;
+  lo[2 * D] = -(vt * vt);
+  a[2 * D + 1] = 0.0;
+  bb[2 * D + 1] = (v6[3] * v6[3] + v6[4] * v6[4]) + v6[5] * v6[5];
+  hi[2 * D + 1] = vr * vr;
+  lo[2 * D + 1] = -(vr * vr);
+}
+
+// Setup for Cartesian paths: s_end = path_start + delta (N-1) as
+// path_timing_trajectory.cc:340-341; the per-sample checks are OR-ed in by k_lp_rows.
+__global__ void k_setup_cartesian(int B, int N, const double *path_start, const double *delta,
+                                  const double *sd_start, const double *sdd_start,
+                                  const double *t_start, Workspace ws) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double s0 = path_start[b];
+  const double s1 = s0 + delta[b] * (N - 1);
+  uint32_t bits = 0;
+  if (s0 >= s1) bits |= kErrSRange;
+  if (sd_start[b] < 0) bits |= kErrSdStartNeg;
+  if (N < 2) bits |= kErrTooFew;
+  ws.err_bits[b] = bits;
+  ws.s_start[b] = s0;
+  ws.s_end[b] = s1;
+  ws.ds[b] = (s1 - s0) / (N - 1);
+  ws.sd_start[b] = sd_start[b];
+  ws.sdd_start[b] = sdd_start ? sdd_start[b] : 0.0;
+  ws.t_start[b] = t_start[b];
+  ws.delta[b] = delta[b];
+}
+
 // ------------------------------------------------ K1 (rows): validation + LP
 // grid = (ceil(N/TPB), B). Dynamic LDS: A,B,LO,HI each [C][TPB].
 template <int WORDS>

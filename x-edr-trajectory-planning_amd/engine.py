@@ -78,6 +78,20 @@ class _RowsInputs(C.Structure):
         "a", "b", "lower", "upper", "s_start", "s_end", "sd_start", "sdd_start", "time_start")]
 
 
+class _CartesianBatch(C.Structure):
+    _fields_ = [("num_paths", C.c_int32), ("num_dofs", C.c_int32), ("num_samples", C.c_int32),
+                ("max_solver_loops", C.c_int32), ("constraint_safety", C.c_double)]
+
+
+_CARTESIAN_INPUT_KEYS = ("ik_positions", "jacobians", "max_velocity", "max_acceleration",
+                         "max_translational_velocity", "max_rotational_velocity", "path_start",
+                         "delta", "sd_start", "sdd_start", "time_start")
+
+
+class _CartesianInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _CARTESIAN_INPUT_KEYS]
+
+
 class _ResampleArgs(C.Structure):
     _fields_ = ([("num_paths", C.c_int32), ("num_samples", C.c_int32), ("num_dofs", C.c_int32),
                  ("max_out", C.c_int32)] +
@@ -96,6 +110,7 @@ ABI_SYMBOLS = [
     "tpamd_engine_reserve", "tpamd_engine_workspace_bytes", "tpamd_time_joint_paths_device",
     "tpamd_time_joint_paths_host", "tpamd_sample_joint_paths_host",
     "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
+    "tpamd_time_cartesian_paths_device", "tpamd_time_cartesian_paths_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
     "tpamd_resample_uniform_host",
     "tpamd_debug_copy_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
@@ -138,6 +153,14 @@ def load_library():
     L.tpamd_optimize_rows_host.restype = i
     L.tpamd_optimize_rows_host.argtypes = [vp, C.POINTER(_RowsBatch), C.POINTER(_RowsInputs),
                                            C.POINTER(_PathOutputs)]
+    L.tpamd_time_cartesian_paths_device.restype = i
+    L.tpamd_time_cartesian_paths_device.argtypes = [vp, C.POINTER(_CartesianBatch),
+                                                    C.POINTER(_CartesianInputs),
+                                                    C.POINTER(_PathOutputs), vp]
+    L.tpamd_time_cartesian_paths_host.restype = i
+    L.tpamd_time_cartesian_paths_host.argtypes = [vp, C.POINTER(_CartesianBatch),
+                                                  C.POINTER(_CartesianInputs),
+                                                  C.POINTER(_PathOutputs)]
     L.tpamd_find_max_sd2_host.restype = i
     L.tpamd_find_max_sd2_host.argtypes = [vp, i, i] + [vp] * 7
     L.tpamd_query_device.restype = i
@@ -264,6 +287,28 @@ class Engine:
             _check(self._lib.tpamd_optimize_rows_device(self._h, C.byref(bt), C.byref(ri),
                                                         C.byref(po), _stream_ptr(stream)),
                    "tpamd_optimize_rows_device")
+
+    # ------------------------------------------------------- Cartesian paths
+    def time_cartesian_paths(self, inputs, outputs, safety=0.8, max_solver_loops=0, stream=None,
+                             host=False):
+        """inputs: ik_positions [B][N][D], jacobians [B][N][6][D], max_velocity,
+        max_acceleration [B][D], max_translational_velocity, max_rotational_velocity,
+        path_start, delta, sd_start, time_start [B] (+ optional sdd_start). outputs as for
+        time_joint_paths (q, if given, receives the IK positions)."""
+        B, N, D = inputs["ik_positions"].shape
+        bt = _CartesianBatch(B, D, N, int(max_solver_loops), float(safety))
+        ci = _CartesianInputs(*[_ptr(inputs.get(k)) for k in _CARTESIAN_INPUT_KEYS])
+        po = _PathOutputs(*[_ptr(outputs.get(k)) for k in (
+            "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
+            "max_time_increment", "status", "sd2")])
+        if host:
+            _check(self._lib.tpamd_time_cartesian_paths_host(self._h, C.byref(bt), C.byref(ci),
+                                                             C.byref(po)),
+                   "tpamd_time_cartesian_paths_host")
+        else:
+            _check(self._lib.tpamd_time_cartesian_paths_device(self._h, C.byref(bt), C.byref(ci),
+                                                               C.byref(po), _stream_ptr(stream)),
+                   "tpamd_time_cartesian_paths_device")
 
     def find_max_sd2(self, a, b, lower, upper):
         """Host numpy [num][C] -> (sd2max, sddmax, sd2zero) [num]."""

@@ -119,3 +119,56 @@ def make_joint_batch(num_paths, num_dofs=7, num_samples=2000, num_waypoints=10,
         sd_start=np.zeros(B), time_start=np.zeros(B),
         num_samples=int(num_samples), safety=float(safety), waypoints=waypoints,
     )
+
+
+def eval_joint_splines(cps, knots, u):
+    """Positions of degree-2 splines at parameters u [B][N] -> [B][N][D] (numpy; only used to
+    make synthetic IK positions, so it need not match the engine bit for bit)."""
+    cps, knots, u = np.asarray(cps), np.asarray(knots), np.asarray(u)
+    B, P, D = cps.shape
+    u = np.clip(u, knots[:, :1], knots[:, -1:])
+    span = np.empty(u.shape, dtype=np.int64)
+    for b in range(B):
+        span[b] = np.clip(np.searchsorted(knots[b], u[b], side="right") - 1, 2, P - 1)
+    bi = np.arange(B)[:, None]
+    k0, k1, k2, k3 = (knots[bi, span + o] for o in (-1, 0, 1, 2))
+    # Cox-de Boor, degree 2, on the span [k1, k2)
+    w1 = (u - k1) / (k2 - k1)
+    n0 = (1.0 - w1) * (k2 - u) / (k2 - k0)
+    n2 = w1 * (u - k1) / (k3 - k1)
+    n1 = 1.0 - n0 - n2
+    return (n0[..., None] * cps[bi, span - 2] + n1[..., None] * cps[bi, span - 1] +
+            n2[..., None] * cps[bi, span])
+
+
+def make_cartesian_batch(num_paths, num_dofs=6, num_samples=2000, num_waypoints=10,
+                         first_path_index=0, safety=0.8):
+    """Synthetic stand-in for BASELINE.json configs[3]: what a TimeableCartesianSplinePath holds
+    after its IK callback ran -- IK positions [B][N][D] (here: a joint-space spline sampled
+    uniformly) and the Jacobian at every sample [B][N][6][D] (here: a smooth function of q
+    with a unit block) -- plus joint and Cartesian velocity limits."""
+    jb = make_joint_batch(num_paths, num_dofs, num_samples, num_waypoints, first_path_index,
+                          safety=safety)
+    B, D, N = int(num_paths), int(num_dofs), int(num_samples)
+    u = jb["delta"][:, None] * np.arange(N)[None, :]
+    q = eval_joint_splines(jb["control_points"], jb["knots"], u)
+    r = np.arange(6)[None, None, :, None]
+    d = np.arange(D)[None, None, None, :]
+    J = 0.25 * np.sin(q[:, :, None, :] * (r + 1.0) + 0.37 * d) + (r == d % 6)
+    idx = np.arange(first_path_index, first_path_index + B, dtype=np.uint64)
+    lim = _splitmix_stream(idx + np.uint64(1 << 40), 2)
+    return dict(
+        ik_positions=np.ascontiguousarray(q), jacobians=np.ascontiguousarray(J),
+        vmax=jb["vmax"], amax=jb["amax"], vtrans=0.6 + 0.9 * lim[:, 0], vrot=0.8 + 1.2 * lim[:, 1],
+        path_start=np.zeros(B), delta=jb["delta"], sd_start=np.zeros(B), time_start=np.zeros(B),
+        num_samples=N, safety=float(safety))
+
+
+def upload_cartesian_batch(batch, device):
+    import torch
+    names = dict(ik_positions="ik_positions", jacobians="jacobians", vmax="max_velocity",
+                 amax="max_acceleration", vtrans="max_translational_velocity",
+                 vrot="max_rotational_velocity", path_start="path_start", delta="delta",
+                 sd_start="sd_start", time_start="time_start")
+    return {v: torch.from_numpy(np.ascontiguousarray(batch[k])).to(device)
+            for k, v in names.items()}
