@@ -82,10 +82,12 @@ __device__ __forceinline__ long long tpamd_stamp() {
 #define TPAMD_T0(var) const long long var = tpamd_stamp()
 #define TPAMD_ACC(slot, var) diag[slot] += tpamd_stamp() - (var)
 #define TPAMD_CNT(slot) diag[slot] += 1
+#define TPAMD_ADD(slot, v) diag[slot] += (v)
 #else
 #define TPAMD_T0(var)
 #define TPAMD_ACC(slot, var)
 #define TPAMD_CNT(slot)
+#define TPAMD_ADD(slot, v)
 #endif
 
 constexpr int kTileSamples = 32;
@@ -132,6 +134,11 @@ struct JointLayout {
   static constexpr int kCandLanes = 2 * D * PARTS;
   static constexpr int kRows16 = (kCandLanes + 15) / 16;     // 16-lane DPP rows in use
   static_assert(kCandLanes <= 64, "candidate lanes must fit one wave");
+  // Chain verification (follow_chain): 16 steps x 4 lanes; lane part p owns candidates
+  // p, p+4, ... and velocity rows p, p+4, ...
+  static constexpr int kChain = 16;
+  static constexpr int CPL = (2 * D + 3) / 4;
+  static constexpr int VPL = (D + 3) / 4;
 };
 
 template <bool MAX>
@@ -167,6 +174,12 @@ struct JointSweep {
   int chk_off[L::RPL];
   int vel_off;
   double row_lo, row_hi;  // AreDerivativesValid: lane j < 2D owns row j
+  // chain verification layout (lane = 4*step + part), see follow_chain
+  double v_lim[L::CPL];   // bound of this lane's i-th candidate (NaN: none)
+  int v_off[L::CPL];      // its row
+  double vv_hi[L::VPL];   // upper bound of this lane's i-th velocity row (+inf: none)
+  int vv_off[L::VPL];
+  double acc_hi[D];       // upper bounds of the acceleration rows (lower = -upper)
 
   struct Rows {
     f64x2 own;            // (q', q'') of the candidate's row
@@ -243,8 +256,10 @@ struct JointSweep {
   }
 
   // FindSddMax (MAX) / FindSddMin, time_optimal_path_timing.cc:638-695.
+  // `win` receives a lane holding the selected candidate (-1: none was admissible); it
+  // seeds the speculation of follow_chain and has no influence on the result.
   template <bool MAX>
-  __device__ __forceinline__ double find_sdd(const Rows &r, double s2) const {
+  __device__ __forceinline__ double find_sdd(const Rows &r, double s2, int &win) const {
     constexpr double kSentinel = MAX ? -DBL_MAX : DBL_MAX;
     // velocity row of this lane: v = q'^2 * sd2 against [0, (vmax*safety)^2]
     const double vv = (r.vel.x * r.vel.x) * s2;
@@ -258,6 +273,7 @@ struct JointSweep {
       bad = bad | (v + kTiny < -chk_hi[k]) | (v - kTiny > chk_hi[k]);
     }
     double best = bad ? kSentinel : sddi;
+    const double mine = best;
     // all parts of a candidate must agree: the group keeps the sentinel if any part set it
     if (L::PARTS >= 2) best = ext2<!MAX>(best, dpp_f64<0xB1>(best));   // xor 1
     if (L::PARTS >= 4) best = ext2<!MAX>(best, dpp_f64<0x4E>(best));   // xor 2
@@ -269,8 +285,49 @@ struct JointSweep {
     double res = readlane_f64(best, 0);
 #pragma unroll
     for (int k = 1; k < L::kRows16; k++) res = ext2<MAX>(res, readlane_f64(best, 16 * k));
+    const unsigned long long holders = __ballot(mine == res);
+    win = __ffsll((long long)holders) - 1;
+    if (res == kSentinel) { res = 0; win = -1; }
+    if (__ballot(vel_bad) != 0ull) { res = 0; win = -1; }
+    return res;
+  }
+
+  // FindSddMax/Min of sample j at sd2 = s2 by the 4 lanes of one chain step (exact, all
+  // candidates against all rows; same operations per candidate as find_sdd).
+  template <bool MAX>
+  __device__ __forceinline__ double find_sdd_quad(int j, double s2) const {
+    constexpr double kSentinel = MAX ? -DBL_MAX : DBL_MAX;
+    const f64x2 *p = record(j);
+    f64x2 row[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) row[d] = p[d];
+    double best = kSentinel;
+#pragma unroll
+    for (int i = 0; i < L::CPL; i++) {
+      const f64x2 own = p[v_off[i]];
+      const double sddi = (v_lim[i] - own.y * s2) / own.x;
+      bool bad = (fabs(own.x) < kTiny) | (sddi != sddi);
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const double v = row[d].x * sddi + row[d].y * s2;
+        bad = bad | (v + kTiny < -acc_hi[d]) | (v - kTiny > acc_hi[d]);
+      }
+      best = ext2<MAX>(best, bad ? kSentinel : sddi);
+    }
+    best = ext2<MAX>(best, dpp_f64<0xB1>(best));   // xor 1
+    best = ext2<MAX>(best, dpp_f64<0x4E>(best));   // xor 2
+    bool vel_bad = false;
+#pragma unroll
+    for (int i = 0; i < L::VPL; i++) {
+      const f64x2 pr = p[vv_off[i]];
+      const double vv = (pr.x * pr.x) * s2;
+      vel_bad = vel_bad | (vv + kTiny < 0.0) | (vv - kTiny > vv_hi[i]);
+    }
+    const unsigned long long vb = __ballot(vel_bad);
+    const bool quad_vel_bad = ((vb >> (lane & ~3)) & 0xFull) != 0ull;
+    double res = best;
     if (res == kSentinel) res = 0;
-    if (__ballot(vel_bad) != 0ull) res = 0;
+    if (quad_vel_bad) res = 0;
     return res;
   }
 
@@ -320,6 +377,7 @@ struct JointSweep {
     double m_n;     // sd2_max[idx + dir]
     double nxt;     // sd2_[idx + dir] as left by earlier extremals (NaN: not visited)
     int t_i, t_n;   // type[idx], type[idx + dir]
+    int win;        // lane of the candidate the last FindSdd step selected (-1: none)
   };
   static constexpr int kContinue = -2;
 
@@ -357,9 +415,12 @@ struct JointSweep {
       TPAMD_CNT(FWD ? 8 : 9);
       sd2tmp = m_n;
       sddtmp = FWD ? 0.5 * (sd2tmp - cur) / ds : 0.5 * (cur - sd2tmp) / ds;
+      c.win = -1;
     } else {
       TPAMD_CNT(FWD ? 10 : 11);
-      sddtmp = uniform_f64(find_sdd<FWD>(use, cur));
+      int win;
+      sddtmp = uniform_f64(find_sdd<FWD>(use, cur, win));
+      c.win = uniform_i32(win);
       sd2tmp = FWD ? cur + two_ds * sddtmp : cur - two_ds * sddtmp;
     }
     if (!isnan(nxt) && (nxt < sd2tmp)) {
@@ -379,8 +440,10 @@ struct JointSweep {
       }
       sd2tmp = m_n;
       sddtmp = sdd_bound;
+      c.win = -1;
     }
     if (sd2tmp < 0) {
+      c.win = -1;
       sd2tmp = 0.0;
       if (FWD) {
         if (idx <= 1) sddtmp = 0.0; else sddtmp = -sd2[idx - 1] / ds;
@@ -443,6 +506,73 @@ struct JointSweep {
     return L;
   }
 
+  // Active-constraint speculation, 16 steps at a time. Along an extremal the candidate that
+  // FindSddMax/Min selects (one row, one bound) usually stays the same for many steps. If it
+  // does, the extremal is the scalar recurrence
+  //     sdd_k = (lim - q''_r[j_k] * sd2_k) / q'_r[j_k],   sd2_{k+1} = sd2_k +- 2 ds sdd_k
+  // (the very operations of the selected candidate in find_sdd and of .cc:794 / :884). The
+  // wave first runs that recurrence for 16 steps (every lane the same arithmetic), then
+  // VERIFIES all 16 steps at once, four lanes per step: the exact FindSddMax/Min of sample j_k
+  // at sd2_k must return the bits of the speculated sdd_k, and none of the special cases of
+  // the scalar step may apply (boundary following .cc:778 / :868, intersection .cc:797 / :887,
+  // limit curve exceeded .cc:806 / :896, negative sd2 .cc:839 / :934, loop end). sd2_k is exact
+  // if steps 0..k-1 verified, so the leading block of verified steps is exactly what the
+  // scalar steps would have produced; it is committed, anything after it is discarded and
+  // redone by the scalar step. Returns the number of steps taken (0..16).
+  template <bool FWD>
+  __device__ __forceinline__ int follow_chain(Carry &c, Prefetch &pf) {
+    constexpr int dir = FWD ? 1 : -1;
+    constexpr int K = L::kChain;
+    const int wl = c.win;
+    const int r = (wl / L::PARTS) >> 1;                  // row of the speculated candidate
+    const double alim = readlane_f64(lim, wl);           // its bound
+    const int j0 = c.idx;
+    int jl = j0 + dir * K;                               // furthest sample touched
+    jl = FWD ? min(jl, N - 1) : max(jl, 0);
+    ensure_tile(j0, dir, pf);
+    ensure_tile(jl, dir, pf);
+    const int k = lane >> 2;
+    int j = j0 + dir * k;                                // this quad's sample
+    const bool in_loop = FWD ? (j < N - 2) : (j > 1);
+    j = min(max(j, 0), N - 1);
+    const int jn = min(max(j + dir, 0), N - 1);
+    const f64x2 arow = record(j)[r];
+    double cur = c.cur;
+    double my_cur = 0.0;
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      const double a = readlane_f64(arow.x, 4 * s), b = readlane_f64(arow.y, 4 * s);
+      if (k == s) my_cur = cur;
+      const double sddv = (alim - b * cur) / a;
+      cur = FWD ? cur + two_ds * sddv : cur - two_ds * sddv;
+    }
+    // every quad redoes its own step from the captured sd2_k (same operations, same bits)
+    const double my_sdd = (alim - arow.y * my_cur) / arow.x;
+    const double my_new = FWD ? my_cur + two_ds * my_sdd : my_cur - two_ds * my_sdd;
+    const double exact = find_sdd_quad<FWD>(j, my_cur);
+    const f64x2 mt_j = record(j)[D], mt_n = record(jn)[D];
+    const int t_j = __double2loint(mt_j.y), t_n = __double2loint(mt_n.y);
+    const double m_j = mt_j.x, m_n = mt_n.x;
+    const double nxt = sd2[jn];
+    const bool same = __double_as_longlong(exact) == __double_as_longlong(my_sdd);
+    const bool riding = is_tiny(my_cur - m_j) && (t_j & kBndTrajectory) && (t_n & kBndTrajectory);
+    const bool special = riding || (!isnan(nxt) && (nxt < my_new)) || (my_new > m_n) || (my_new < 0) ||
+                         isnan(my_new);
+    const bool ok = in_loop && same && !special;
+    const unsigned long long okm = __ballot(ok);
+    const unsigned long long miss = ~okm & 0x1111111111111111ull;   // part-0 lanes
+    const int Lc = miss ? ((__ffsll((long long)miss) - 1) >> 2) : K;
+    if (Lc == 0) return 0;
+    if ((lane & 3) == 0 && k < Lc) {
+      sd2[j + dir] = my_new;
+      sdd_g[j] = my_sdd;
+    }
+    wave_lds_sync();
+    c.idx = j0 + dir * Lc;
+    c.cur = readlane_f64(my_new, 4 * (Lc - 1));
+    return Lc;
+  }
+
   // (Re)start the carried state at sample idx: tiles, rows, neighbours.
   template <bool FWD>
   __device__ __forceinline__ void init_carry(int idx, Carry &c, Rows &rows, Prefetch &pf, bool load_cur) {
@@ -459,6 +589,7 @@ struct JointSweep {
     c.m_i = uniform_f64(m0); c.m_n = uniform_f64(m1);
     c.t_i = uniform_i32(t0); c.t_n = uniform_i32(t1);
     c.nxt = uniform_f64(sd2[idx + dir]);
+    c.win = -1;
   }
 
   // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952) otherwise.
@@ -487,6 +618,8 @@ struct JointSweep {
     pf.tag = -1;
     Carry c;
     init_carry<FWD>(idx_start, c, rows_a, pf, true);
+    bool trust = true;
+    int last_win = -1;
     for (;;) {
 #define TPAMD_TRY_FOLLOW()                                                                   \
   if (is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {      \
@@ -499,9 +632,31 @@ struct JointSweep {
       continue;                                                                              \
     }                                                                                        \
   }
+// After a FindSdd step selected a candidate: speculate on it (follow_chain) as long as whole
+// blocks verify. `trust` drops after a block that verified nothing; it takes two scalar
+// steps selecting the same candidate to try again.
+#define TPAMD_TRY_CHAIN()                                                                    \
+  if (c.win >= 0 && (trust || c.win == last_win)) {                                          \
+    int total = 0, run;                                                                      \
+    do {                                                                                     \
+      run = uniform_i32(follow_chain<FWD>(c, pf));                                           \
+      total += run;                                                                          \
+    } while (run == L::kChain && (FWD ? (c.idx < N - 2) : (c.idx > 1)));                     \
+    trust = total > 0;                                                                       \
+    last_win = -1;                                                                           \
+    if (total > 0) {                                                                         \
+      TPAMD_ADD(FWD ? 14 : 15, total);                                                       \
+      if (FWD ? !(c.idx < N - 2) : !(c.idx > 1)) return FWD ? N - 1 : 0;                     \
+      init_carry<FWD>(c.idx, c, rows_a, pf, false);                                          \
+      continue;                                                                              \
+    }                                                                                        \
+  } else {                                                                                   \
+    last_win = c.win;                                                                        \
+  }
       TPAMD_TRY_FOLLOW();
       int r = extremal_step<FWD>(c, rows_a, rows_b, pf, idx_start, pair_signal);
       if (r != kContinue) return r;
+      TPAMD_TRY_CHAIN();
       if (is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {
         // a run starts here: restart the loop (it re-stages into rows_a)
         load_rows(c.idx, rows_a);
@@ -509,7 +664,9 @@ struct JointSweep {
       }
       r = extremal_step<FWD>(c, rows_b, rows_a, pf, idx_start, pair_signal);
       if (r != kContinue) return r;
+      TPAMD_TRY_CHAIN();
     }
+#undef TPAMD_TRY_CHAIN
 #undef TPAMD_TRY_FOLLOW
 #undef TPAMD_PAIR_SIGNAL
   }
@@ -619,6 +776,28 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   }
   S.row_lo = (lane < 2 * D) ? lim_lo[lane] : 0.0;
   S.row_hi = (lane < 2 * D) ? lim_hi[lane] : 0.0;
+  {
+    typedef JointLayout<D> L;
+    const double kInf = __longlong_as_double(0x7ff0000000000000LL);
+    const int p = lane & 3;
+#pragma unroll
+    for (int i = 0; i < L::CPL; i++) {
+      const int cand = p + 4 * i;
+      const bool has = cand < 2 * D;
+      const int row = has ? (cand >> 1) : 0;
+      S.v_off[i] = row;
+      S.v_lim[i] = has ? ((cand & 1) ? lim_hi[row] : lim_lo[row]) : qnan();
+    }
+#pragma unroll
+    for (int i = 0; i < L::VPL; i++) {
+      const int row = p + 4 * i;
+      const bool has = row < D;
+      S.vv_off[i] = has ? row : 0;
+      S.vv_hi[i] = has ? lim_hi[D + row] : kInf;
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) S.acc_hi[d] = lim_hi[d];
+  }
 
   double *sd2 = S.sd2;
   const double sd_start = ws.sd_start[b];
