@@ -488,33 +488,90 @@ __device__ __forceinline__ double final_m(const Workspace &ws, size_t pb, int N,
   return ws.m0[pb + j];
 }
 
+// FindSddMax and FindSddMin of one sample by a whole wave: candidates over lanes, every
+// lane validates its candidate against all rows, wave reductions keep the extremes (the
+// value find_sdd_both returns: its visiting order and pruning do not change the result;
+// a NaN candidate is never selected there because it fails both comparisons).
+template <class R>
+__device__ __forceinline__ void wave_find_sdd_both(const R &r, int C, double sd2, int lane,
+                                                   double *sdd_max, double *sdd_min) {
+  double smax = -DBL_MAX, smin = DBL_MAX;
+  for (int c = lane; c < 2 * C; c += 64) {
+    const int i = c >> 1;
+    const double A = r.a(i);
+    if (!is_tiny(A)) {
+      const double bs = r.b(i) * sd2;
+      const double lim = (c & 1) ? r.hi(i) : r.lo(i);
+      const double sddi = (lim - bs) / A;
+      if ((sddi == sddi) && rows_valid(r, C, sddi, sd2)) {
+        if (sddi > smax) smax = sddi;
+        if (sddi < smin) smin = sddi;
+      }
+    }
+  }
+  smax = wave_max_f64(smax);
+  smin = wave_min_f64(smin);
+  if (smax == -DBL_MAX) smax = 0;
+  if (smin == DBL_MAX) smin = 0;
+  *sdd_max = smax;
+  *sdd_min = smin;
+}
+
+// Block = 256 threads, one per sample. The few samples whose boundary value was replaced
+// in pass 3 need FindSddMax/Min at the new value; they are collected in LDS and each is
+// evaluated by a whole wave (the per-thread version made every wave holding one such
+// sample run the full candidate loop).
 template <class Source>
-__global__ void k_boundary_final(int stride, Source src, Workspace ws) {
+__global__ void __launch_bounds__(256) k_boundary_final(int stride, Source src, Workspace ws) {
+  __shared__ int s_count;
+  __shared__ int s_list[256];
+  __shared__ double s_X[256], s_Y[256];
   const int b = blockIdx.y;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x * 256 + tid;
   const int N = path_samples(ws, b, stride);
-  if (j >= N) return;
+  const bool active = j < N;
   const size_t pb = (size_t)b * stride;
   const uint8_t *ff = ws.fix_flag + pb;
   const uint8_t *at = ws.at0 + pb;
-  double m, X, Y;
-  const bool f_next = (j + 1 <= N - 2) && ff[j + 1];
-  const bool f_self = ff[j];
-  const bool f_prev = (j >= 1) && ff[j - 1];
-  if (f_next || (!f_self && f_prev)) {
-    m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
-  } else if (f_self) {
-    m = ws.fix_val[pb + j];
-    const auto r = src.at(b, stride, j);
-    if (Source::kJoint) find_sdd_both_joint(r, src.rows() / 2, m, &X, &Y);
-    else find_sdd_both(r, src.rows(), m, &X, &Y);
-  } else if (iso_at(at, N, j + 1)) {
-    m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
-  } else if (iso_at(at, N, j - 1)) {
-    m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Xz[pb + j];  // sic, .cc:1394-1395
-  } else {
-    m = ws.m0[pb + j]; X = ws.X0[pb + j]; Y = ws.Y0[pb + j];
+  double m = 0.0, X = 0.0, Y = 0.0;
+  bool refit = false;
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  if (active) {
+    const bool f_next = (j + 1 <= N - 2) && ff[j + 1];
+    const bool f_self = ff[j];
+    const bool f_prev = (j >= 1) && ff[j - 1];
+    if (f_next || (!f_self && f_prev)) {
+      m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
+    } else if (f_self) {
+      m = ws.fix_val[pb + j];
+      refit = true;
+      s_list[atomicAdd(&s_count, 1)] = tid;
+    } else if (iso_at(at, N, j + 1)) {
+      m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
+    } else if (iso_at(at, N, j - 1)) {
+      m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Xz[pb + j];  // sic, .cc:1394-1395
+    } else {
+      m = ws.m0[pb + j]; X = ws.X0[pb + j]; Y = ws.Y0[pb + j];
+    }
   }
+  __syncthreads();
+  {
+    const int count = s_count;
+    const int lane = tid & 63;
+    for (int it = tid >> 6; it < count; it += 4) {
+      const int t = s_list[it];
+      const int jj = blockIdx.x * 256 + t;
+      const auto r = src.at(b, stride, jj);
+      double x, y;
+      wave_find_sdd_both(r, src.rows(), ws.fix_val[pb + jj], lane, &x, &y);
+      if (lane == 0) { s_X[t] = x; s_Y[t] = y; }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  if (refit) { X = s_X[tid]; Y = s_Y[tid]; }
   ws.m[pb + j] = m;
   ws.X[pb + j] = X;
   ws.Y[pb + j] = Y;

@@ -640,6 +640,8 @@ struct JointSweep {
     int total = 0, run;                                                                      \
     do {                                                                                     \
       run = uniform_i32(follow_chain<FWD>(c, pf));                                           \
+      TPAMD_CNT(6);                                                                          \
+      TPAMD_ADD(7, run == 0 ? 1 : 0);                                                        \
       total += run;                                                                          \
     } while (run == L::kChain && (FWD ? (c.idx < N - 2) : (c.idx > 1)));                     \
     trust = total > 0;                                                                       \
