@@ -178,8 +178,8 @@ struct JointSweep {
   double v_lim[L::CPL];   // bound of this lane's i-th candidate (NaN: none)
   int v_off[L::CPL];      // its row
   double vv_hi[L::VPL];   // upper bound of this lane's i-th velocity row (+inf: none)
+  double va_hi[L::VPL];   // upper bound of the acceleration row of the same joint (+inf: none)
   int vv_off[L::VPL];
-  double acc_hi[D];       // upper bounds of the acceleration rows (lower = -upper)
 
   struct Rows {
     f64x2 own;            // (q', q'') of the candidate's row
@@ -292,43 +292,39 @@ struct JointSweep {
     return res;
   }
 
-  // FindSddMax/Min of sample j at sd2 = s2 by the 4 lanes of one chain step (exact, all
-  // candidates against all rows; same operations per candidate as find_sdd).
+  // Chain verification of one step by its 4 lanes: is `sddw` -- the candidate of row r at
+  // sample j, sd2 = s2, already computed with the reference's operations -- exactly what
+  // FindSddMax (MAX) / FindSddMin returns there? Yes if (1) it is admissible: all rows
+  // hold, acceleration rows split over the 4 lanes, velocity rows likewise; and (2) no
+  // other candidate beats it: every candidate that compares better must be inadmissible,
+  // which is checked against ONE row only, row r (the one the speculated candidate sits
+  // on: anything better than it normally violates that row). A better candidate that
+  // passes row r makes the answer "unknown" (false), never wrong: the step then falls to
+  // the scalar code.
   template <bool MAX>
-  __device__ __forceinline__ double find_sdd_quad(int j, double s2) const {
-    constexpr double kSentinel = MAX ? -DBL_MAX : DBL_MAX;
+  __device__ __forceinline__ bool chain_step_exact(int j, int r, double hi_r, f64x2 arow, double s2,
+                                                   double sddw) const {
     const f64x2 *p = record(j);
-    f64x2 row[D];
+    bool bad = false;
 #pragma unroll
-    for (int d = 0; d < D; d++) row[d] = p[d];
-    double best = kSentinel;
+    for (int i = 0; i < L::VPL; i++) {       // winner against this lane's share of the rows
+      const f64x2 pr = p[vv_off[i]];
+      const double v = pr.x * sddw + pr.y * s2;
+      bad = bad | (v + kTiny < -va_hi[i]) | (v - kTiny > va_hi[i]);
+      const double vv = (pr.x * pr.x) * s2;
+      bad = bad | (vv + kTiny < 0.0) | (vv - kTiny > vv_hi[i]);
+    }
 #pragma unroll
-    for (int i = 0; i < L::CPL; i++) {
+    for (int i = 0; i < L::CPL; i++) {       // this lane's other candidates
       const f64x2 own = p[v_off[i]];
       const double sddi = (v_lim[i] - own.y * s2) / own.x;
-      bool bad = (fabs(own.x) < kTiny) | (sddi != sddi);
-#pragma unroll
-      for (int d = 0; d < D; d++) {
-        const double v = row[d].x * sddi + row[d].y * s2;
-        bad = bad | (v + kTiny < -acc_hi[d]) | (v - kTiny > acc_hi[d]);
-      }
-      best = ext2<MAX>(best, bad ? kSentinel : sddi);
+      const bool better = MAX ? (sddi > sddw) : (sddi < sddw);
+      const double v = arow.x * sddi + arow.y * s2;
+      const bool passes = !((v + kTiny < -hi_r) | (v - kTiny > hi_r));
+      bad = bad | (better & passes & !(fabs(own.x) < kTiny));
     }
-    best = ext2<MAX>(best, dpp_f64<0xB1>(best));   // xor 1
-    best = ext2<MAX>(best, dpp_f64<0x4E>(best));   // xor 2
-    bool vel_bad = false;
-#pragma unroll
-    for (int i = 0; i < L::VPL; i++) {
-      const f64x2 pr = p[vv_off[i]];
-      const double vv = (pr.x * pr.x) * s2;
-      vel_bad = vel_bad | (vv + kTiny < 0.0) | (vv - kTiny > vv_hi[i]);
-    }
-    const unsigned long long vb = __ballot(vel_bad);
-    const bool quad_vel_bad = ((vb >> (lane & ~3)) & 0xFull) != 0ull;
-    double res = best;
-    if (res == kSentinel) res = 0;
-    if (quad_vel_bad) res = 0;
-    return res;
+    const unsigned long long bm = __ballot(bad);
+    return ((bm >> (lane & ~3)) & 0xFull) == 0ull;
   }
 
   // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
@@ -537,28 +533,47 @@ struct JointSweep {
     j = min(max(j, 0), N - 1);
     const int jn = min(max(j + dir, 0), N - 1);
     const f64x2 arow = record(j)[r];
+    const double hi_r = readlane_f64(row_hi, r);
+    // The recurrence. Its division is done with a reciprocal refined per lane beforehand
+    // (the denominator-only part of the IEEE division sequence: v_rcp_f64 + two Newton
+    // steps), so that one step is 7 dependent operations. Whether that quotient is the
+    // correctly rounded one is NOT assumed: every quad recomputes its step with the real
+    // division below and the chain value must match it bit for bit.
+    double y = __builtin_amdgcn_rcp(arow.x);
+    {
+      double e = __builtin_fma(-arow.x, y, 1.0);
+      y = __builtin_fma(y, e, y);
+      e = __builtin_fma(-arow.x, y, 1.0);
+      y = __builtin_fma(y, e, y);
+    }
     double cur = c.cur;
     double my_cur = 0.0;
 #pragma unroll
     for (int s = 0; s < K; s++) {
       const double a = readlane_f64(arow.x, 4 * s), b = readlane_f64(arow.y, 4 * s);
+      const double ys = readlane_f64(y, 4 * s);
       if (k == s) my_cur = cur;
-      const double sddv = (alim - b * cur) / a;
-      cur = FWD ? cur + two_ds * sddv : cur - two_ds * sddv;
+      const double n = alim - b * cur;
+      const double q0 = n * ys;
+      const double rem = __builtin_fma(-a, q0, n);
+      const double q = __builtin_fma(rem, ys, q0);
+      cur = FWD ? cur + two_ds * q : cur - two_ds * q;
     }
-    // every quad redoes its own step from the captured sd2_k (same operations, same bits)
+    // every quad redoes its own step from the captured sd2_k with the reference's operations
     const double my_sdd = (alim - arow.y * my_cur) / arow.x;
     const double my_new = FWD ? my_cur + two_ds * my_sdd : my_cur - two_ds * my_sdd;
-    const double exact = find_sdd_quad<FWD>(j, my_cur);
+    double chain_next = __shfl_down(my_cur, 4, 64);      // what the recurrence fed to step k+1
+    if (k == K - 1) chain_next = cur;
+    const bool exact = (__double_as_longlong(chain_next) == __double_as_longlong(my_new)) &&
+                       chain_step_exact<FWD>(j, r, hi_r, arow, my_cur, my_sdd);
     const f64x2 mt_j = record(j)[D], mt_n = record(jn)[D];
     const int t_j = __double2loint(mt_j.y), t_n = __double2loint(mt_n.y);
     const double m_j = mt_j.x, m_n = mt_n.x;
     const double nxt = sd2[jn];
-    const bool same = __double_as_longlong(exact) == __double_as_longlong(my_sdd);
     const bool riding = is_tiny(my_cur - m_j) && (t_j & kBndTrajectory) && (t_n & kBndTrajectory);
     const bool special = riding || (!isnan(nxt) && (nxt < my_new)) || (my_new > m_n) || (my_new < 0) ||
                          isnan(my_new);
-    const bool ok = in_loop && same && !special;
+    const bool ok = in_loop && exact && !special;
     const unsigned long long okm = __ballot(ok);
     const unsigned long long miss = ~okm & 0x1111111111111111ull;   // part-0 lanes
     const int Lc = miss ? ((__ffsll((long long)miss) - 1) >> 2) : K;
@@ -796,9 +811,8 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
       const bool has = row < D;
       S.vv_off[i] = has ? row : 0;
       S.vv_hi[i] = has ? lim_hi[D + row] : kInf;
+      S.va_hi[i] = has ? lim_hi[row] : kInf;
     }
-#pragma unroll
-    for (int d = 0; d < D; d++) S.acc_hi[d] = lim_hi[d];
   }
 
   double *sd2 = S.sd2;
