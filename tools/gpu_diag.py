@@ -16,9 +16,9 @@ for _ in range(3):
     E.time_joint_paths(inp, out, N)
 torch.cuda.synchronize()
 d = E.debug_diag(B).astype(np.float64)
-names = {0: "fwd extremals", 1: "bwd extremals", 2: "crit search", 3: "tail", 4: "find_sdd steps",
+names = {0: "fwd extremals", 1: "bwd extremals", 2: "crit search", 3: "tail", 4: "chain cycles",
          5: "whole loop", 6: "chain blocks", 7: "chain blocks, 0 verified", 8: "n boundary fwd", 9: "n boundary bwd",
-         10: "n findsdd fwd", 11: "n findsdd bwd", 12: "tile fills", 13: "tile fills w/o prefetch",
+         10: "n findsdd fwd", 11: "loops", 12: "tile fills", 13: "tile fills w/o prefetch",
          14: "chain steps fwd", 15: "chain steps bwd"}
 for k, n in names.items():
     print("%-16s mean %12.0f  min %12.0f  max %12.0f" % (n, d[:, k].mean(), d[:, k].min(), d[:, k].max()))

@@ -134,11 +134,18 @@ struct JointLayout {
   static constexpr int kCandLanes = 2 * D * PARTS;
   static constexpr int kRows16 = (kCandLanes + 15) / 16;     // 16-lane DPP rows in use
   static_assert(kCandLanes <= 64, "candidate lanes must fit one wave");
-  // Chain verification (follow_chain): 16 steps x 4 lanes; lane part p owns candidates
-  // p, p+4, ... and velocity rows p, p+4, ...
-  static constexpr int kChain = 16;
-  static constexpr int CPL = (2 * D + 3) / 4;
-  static constexpr int VPL = (D + 3) / 4;
+  // Chain verification (follow_chain): kChain steps x GRP lanes; lane part p of a step's
+  // group owns candidates p, p+GRP, ... and rows p, p+GRP, ...
+#ifndef TPAMD_CHAIN_STEPS
+#define TPAMD_CHAIN_STEPS 16
+#endif
+  static constexpr int kChain = TPAMD_CHAIN_STEPS;
+  static constexpr int GRP = 64 / kChain;
+  static constexpr int CPL = (2 * D + GRP - 1) / GRP;
+  static constexpr int VPL = (D + GRP - 1) / GRP;
+  static constexpr unsigned long long kPart0 =
+      (GRP == 4) ? 0x1111111111111111ull : ((GRP == 2) ? 0x5555555555555555ull : ~0ull);
+  static_assert(GRP == 1 || GRP == 2 || GRP == 4, "chain steps must be 16, 32 or 64");
 };
 
 template <bool MAX>
@@ -324,7 +331,7 @@ struct JointSweep {
       bad = bad | (better & passes & !(fabs(own.x) < kTiny));
     }
     const unsigned long long bm = __ballot(bad);
-    return ((bm >> (lane & ~3)) & 0xFull) == 0ull;
+    return ((bm >> (lane & ~(L::GRP - 1))) & ((1ull << L::GRP) - 1ull)) == 0ull;
   }
 
   // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
@@ -527,8 +534,9 @@ struct JointSweep {
     jl = FWD ? min(jl, N - 1) : max(jl, 0);
     ensure_tile(j0, dir, pf);
     ensure_tile(jl, dir, pf);
-    const int k = lane >> 2;
-    int j = j0 + dir * k;                                // this quad's sample
+    constexpr int G = L::GRP;
+    const int k = lane / G;
+    int j = j0 + dir * k;                                // this group's sample
     const bool in_loop = FWD ? (j < N - 2) : (j > 1);
     j = min(max(j, 0), N - 1);
     const int jn = min(max(j + dir, 0), N - 1);
@@ -550,8 +558,8 @@ struct JointSweep {
     double my_cur = 0.0;
 #pragma unroll
     for (int s = 0; s < K; s++) {
-      const double a = readlane_f64(arow.x, 4 * s), b = readlane_f64(arow.y, 4 * s);
-      const double ys = readlane_f64(y, 4 * s);
+      const double a = readlane_f64(arow.x, G * s), b = readlane_f64(arow.y, G * s);
+      const double ys = readlane_f64(y, G * s);
       if (k == s) my_cur = cur;
       const double n = alim - b * cur;
       const double q0 = n * ys;
@@ -562,7 +570,7 @@ struct JointSweep {
     // every quad redoes its own step from the captured sd2_k with the reference's operations
     const double my_sdd = (alim - arow.y * my_cur) / arow.x;
     const double my_new = FWD ? my_cur + two_ds * my_sdd : my_cur - two_ds * my_sdd;
-    double chain_next = __shfl_down(my_cur, 4, 64);      // what the recurrence fed to step k+1
+    double chain_next = __shfl_down(my_cur, G, 64);      // what the recurrence fed to step k+1
     if (k == K - 1) chain_next = cur;
     const bool exact = (__double_as_longlong(chain_next) == __double_as_longlong(my_new)) &&
                        chain_step_exact<FWD>(j, r, hi_r, arow, my_cur, my_sdd);
@@ -575,16 +583,16 @@ struct JointSweep {
                          isnan(my_new);
     const bool ok = in_loop && exact && !special;
     const unsigned long long okm = __ballot(ok);
-    const unsigned long long miss = ~okm & 0x1111111111111111ull;   // part-0 lanes
-    const int Lc = miss ? ((__ffsll((long long)miss) - 1) >> 2) : K;
+    const unsigned long long miss = ~okm & L::kPart0;   // part-0 lanes
+    const int Lc = miss ? ((__ffsll((long long)miss) - 1) / G) : K;
     if (Lc == 0) return 0;
-    if ((lane & 3) == 0 && k < Lc) {
+    if ((lane & (G - 1)) == 0 && k < Lc) {
       sd2[j + dir] = my_new;
       sdd_g[j] = my_sdd;
     }
     wave_lds_sync();
     c.idx = j0 + dir * Lc;
-    c.cur = readlane_f64(my_new, 4 * (Lc - 1));
+    c.cur = readlane_f64(my_new, G * (Lc - 1));
     return Lc;
   }
 
@@ -654,7 +662,7 @@ struct JointSweep {
   if (c.win >= 0 && (trust || c.win == last_win)) {                                          \
     int total = 0, run;                                                                      \
     do {                                                                                     \
-      run = uniform_i32(follow_chain<FWD>(c, pf));                                           \
+      { TPAMD_T0(tc_); run = uniform_i32(follow_chain<FWD>(c, pf)); TPAMD_ACC(4, tc_); }     \
       TPAMD_CNT(6);                                                                          \
       TPAMD_ADD(7, run == 0 ? 1 : 0);                                                        \
       total += run;                                                                          \
@@ -694,30 +702,59 @@ struct JointSweep {
   //  2. first idx >= c0 whose sd2 is already set -> e (none: -1); the answer is the
   //     last idx in (c0, e] with sd2_max[idx] == sd2_max_for_sdd0[0] (sic, index 0,
   //     .cc:710; cached as bit kBndEqualsZ00 of the type byte), else c0.
+  // Each pass of the scan loops covers 256 samples (four 64-sample ballots whose LDS reads
+  // are issued together).
   __device__ __forceinline__ int next_critical_point(int idx_lo, int idx_hi) const {
     int c0 = -1;
-    for (int base = idx_lo + 1; base <= idx_hi && c0 < 0; base += 64) {
-      const int idx = base + lane;
-      const bool hit = (idx <= idx_hi) && (typel[idx] & (kBndSource | kBndTrajectory));
-      const unsigned long long mask = __ballot(hit);
-      if (mask) c0 = base + __ffsll((long long)mask) - 1;
+    for (int base = idx_lo + 1; base <= idx_hi && c0 < 0; base += 256) {
+      uint8_t ty[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ty[u] = typel[min(base + 64 * u + lane, N - 1)];   // unconditional loads
+      unsigned long long mask[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = base + 64 * u + lane;
+        mask[u] = __ballot((idx <= idx_hi) & ((ty[u] & (kBndSource | kBndTrajectory)) != 0));
+      }
+#pragma unroll
+      for (int u = 3; u >= 0; u--)
+        if (mask[u]) c0 = base + 64 * u + __ffsll((long long)mask[u]) - 1;
     }
     if (c0 < 0) return -1;
     int crit = c0;
-    for (int base = c0; base <= idx_hi; base += 64) {
-      const int idx = base + lane;
-      const bool in = idx <= idx_hi;
-      const bool set = in && !isnan(sd2[idx]);
-      const bool isol = in && (idx > c0) && (typel[idx] & kBndEqualsZ00);
-      const unsigned long long mset = __ballot(set);
-      unsigned long long miso = __ballot(isol);
-      if (mset) {
-        const int e = __ffsll((long long)mset) - 1;
-        if (e < 63) miso &= (2ull << e) - 1ull;
-        if (miso) crit = base + 63 - __clzll((long long)miso);
-        return crit;
+    for (int base = c0; base <= idx_hi; base += 256) {
+      uint8_t ty[4];
+      int hi32[4];
+      unsigned int lo32[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int ic = min(base + 64 * u + lane, N - 1);
+        ty[u] = typel[ic];
+        const double v = sd2[ic];
+        hi32[u] = __double2hiint(v);
+        lo32[u] = (unsigned int)__double2loint(v);
       }
-      if (miso) crit = base + 63 - __clzll((long long)miso);
+      unsigned long long mset[4], miso[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = base + 64 * u + lane;
+        const bool in = idx <= idx_hi;
+        // !isnan(v): not (exponent all ones and mantissa non-zero)
+        const bool nan = ((hi32[u] & 0x7ff00000) == 0x7ff00000) & (((hi32[u] & 0x000fffff) | lo32[u]) != 0u);
+        mset[u] = __ballot(in & !nan);
+        miso[u] = __ballot(in & (idx > c0) & ((ty[u] & kBndEqualsZ00) != 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (mset[u]) {
+          const int e = __ffsll((long long)mset[u]) - 1;
+          unsigned long long mi = miso[u];
+          if (e < 63) mi &= (2ull << e) - 1ull;
+          if (mi) crit = base + 64 * u + 63 - __clzll((long long)mi);
+          return crit;
+        }
+        if (miso[u]) crit = base + 64 * u + 63 - __clzll((long long)miso[u]);
+      }
     }
     return -1;
   }
@@ -796,10 +833,10 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   {
     typedef JointLayout<D> L;
     const double kInf = __longlong_as_double(0x7ff0000000000000LL);
-    const int p = lane & 3;
+    const int p = lane & (L::GRP - 1);
 #pragma unroll
     for (int i = 0; i < L::CPL; i++) {
-      const int cand = p + 4 * i;
+      const int cand = p + L::GRP * i;
       const bool has = cand < 2 * D;
       const int row = has ? (cand >> 1) : 0;
       S.v_off[i] = row;
@@ -807,7 +844,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     }
 #pragma unroll
     for (int i = 0; i < L::VPL; i++) {
-      const int row = p + 4 * i;
+      const int row = p + L::GRP * i;
       const bool has = row < D;
       S.vv_off[i] = has ? row : 0;
       S.vv_hi[i] = has ? lim_hi[D + row] : kInf;
@@ -866,6 +903,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   if (max_loops <= 0) max_loops = max(100, 10 * N);   // path_timing_trajectory.cc:398-400
   for (int loop = 0; loop < max_loops; loop++) {
     if (iforw_hi >= icrit_hi) break;
+    TPAMD_CNT(11);
     if (WAVES == 2) __syncthreads();   // sd2 writes of the other wave / the NaN mark are visible
     {
       TPAMD_T0(t0);

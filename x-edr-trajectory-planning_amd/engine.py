@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libtpamd.so")
+_SO = os.environ.get("TPAMD_LIBRARY") or os.path.join(_CSRC, "libtpamd.so")   # override: A/B builds
 _SOURCES = ["tpamd_capi.hip", "tpamd_kernels.h", "tpamd_device.h", "tpamd_sweep_joint.h"]
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "tpamd.h")
 
