@@ -92,12 +92,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal on a one-GPU box: TPAMD_BENCH_DEVICE=0 puts every rank on the same card
+    dev_index = int(os.environ.get("TPAMD_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("TPAMD_BENCH_BACKEND", "nccl")   # "gloo": one-GPU rehearsal only
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     eng = importlib.import_module(PKG + ".engine")
     syn = importlib.import_module(PKG + ".synthetic")
@@ -113,22 +119,34 @@ def main():
     lo, hi = shd.shard_bounds(total_paths, world, rank)
     batch = syn.make_joint_batch(hi - lo, D, N, first_path_index=lo)
     P = batch["control_points"].shape[1]
-    E = eng.Engine(local_rank)
+    E = eng.Engine(dev_index)
     E.reserve(B, N, 2 * D)
     inp = eng.upload_joint_batch(batch, dev)
-    # timing profile packed as [4][B][N] so that the multi-GPU collection is ONE gather
-    packed = torch.empty(4, B, N, dtype=torch.float64, device=dev)
-    out = eng.alloc_joint_outputs(B, N, D, dev)
-    out["time"], out["s"], out["sd"], out["sdd"] = packed[0], packed[1], packed[2], packed[3]
+    # timing profile packed as [4][B][N] so that the multi-GPU collection is ONE gather per
+    # batch; two output buffers, so that the gather of batch k (rank 0's inbound xGMI links)
+    # overlaps the solve of batch k+1
+    G = shd.PipelinedGather((4, B, N), torch.float64, dev, depth=2)
+    shared = eng.alloc_joint_outputs(B, N, D, dev)
+    outs = []
+    for slot in range(2):
+        o = dict(shared)
+        p = G.send[slot]
+        o["time"], o["s"], o["sd"], o["sdd"] = p[0], p[1], p[2], p[3]
+        outs.append(o)
+    counter = [0]
 
     def step():
-        E.time_joint_paths(inp, out, N)
-        if distributed:
-            shd.gather_packed(packed, dst=0)
+        k = counter[0]
+        counter[0] += 1
+        G.buffer(k)                       # the gather that last read this buffer is done
+        E.time_joint_paths(inp, outs[k % 2], N)
+        G.launch(k)
 
     for _ in range(args.warmup):
         step()
+    G.drain()
     torch.cuda.synchronize()
+    out = outs[0]
     ok = int((out["status"] == 0).sum())
 
     timing = not args.no_kernel_timing
@@ -140,6 +158,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    G.drain()                             # every batch's gather has landed on rank 0
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -195,7 +214,9 @@ def main():
                        "paths_per_gpu": B, "total_paths": total_paths, "num_dofs": D,
                        "num_samples": N, "solved_paths": solved,
                        "gather": ("one RCCL gather of the packed timing profile "
-                                  "(t,s,sd,sdd: 4*N*8 B/path) to rank 0 per step"
+                                  "(t,s,sd,sdd: 4*N*8 B/path) to rank 0 per step, overlapped "
+                                  "with the next step's solve (double-buffered), all inside "
+                                  "the timed region"
                                   if distributed else "none (single GPU)")},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -50,6 +50,50 @@ def _worker(rank, world, port, total, N, ragged, q):
         dist.destroy_process_group()
 
 
+def _pipeline_worker(rank, world, port, B, N, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = importlib.import_module(PKG_NAME + ".sharding")
+    try:
+        g = sh.PipelinedGather((4, B, N), torch.float64, "cpu", depth=2)
+        seen = []
+        for k in range(steps):
+            buf = g.buffer(k)
+            if rank == 0 and k >= 2:           # the result of batch k-2 is complete by now
+                seen.append(g.result(k - 2).clone().numpy())
+            buf.copy_(torch.full((4, B, N), float(1000 * k + rank)))   # "solve" batch k
+            g.launch(k)
+        g.drain()
+        if rank == 0:
+            for k in range(max(0, steps - 2), steps):
+                seen.append(g.result(k).clone().numpy())
+            q.put(seen)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_keeps_batches_apart():
+    world, B, N, steps = 2, 3, 5, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, B, N, steps, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(seen) == steps
+    for k, full in enumerate(seen):
+        assert full.shape == (world, 4, B, N)
+        for r in range(world):
+            assert (full[r] == 1000 * k + r).all(), (k, r)
+
+
 @pytest.mark.parametrize("ragged", [False, True])
 def test_two_rank_gather(ragged):
     world, total, N = 2, 10, 7

@@ -58,6 +58,61 @@ def gather_packed(packed, dst=0, group=None):
     return None
 
 
+class PipelinedGather:
+    """The single gather per batch, overlapped with the next batch's solve.
+
+    Rank `dst` receives 7/8 of every batch through its inbound xGMI links (64 KB per path
+    for the packed timing profile), which takes about as long as solving a shard
+    (SURVEY.md 8e), so the gather of batch k runs asynchronously while batch k+1 is being
+    solved into the other of `depth` output buffers. Usage per batch k:
+        buf = g.buffer(k)          # waits until the gather that last read it is done
+        ... solve into buf ...
+        g.launch(k)                # ONE async gather of buf (RCCL stream)
+    and g.drain() before results are read / timing stops. On `dst`, result(k) is the
+    [world, *shape] tensor of batch k (valid after the gather completed)."""
+
+    def __init__(self, shape, dtype, device, depth=2, dst=0, group=None):
+        self.group, self.dst, self.depth = group, dst, depth
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self.recv = None
+        if self.world > 1 and self.rank == dst:
+            self.recv = [torch.empty((self.world,) + tuple(shape), dtype=dtype, device=device)
+                         for _ in range(depth)]
+        self.work = [None] * depth
+
+    def buffer(self, k):
+        slot = k % self.depth
+        if self.work[slot] is not None:
+            self.work[slot].wait()      # stream-level wait for NCCL, blocking wait for gloo
+            self.work[slot] = None
+        return self.send[slot]
+
+    def launch(self, k):
+        slot = k % self.depth
+        if self.world == 1:
+            return
+        if self.rank == self.dst:
+            self.work[slot] = dist.gather(self.send[slot], gather_list=list(self.recv[slot].unbind(0)),
+                                          dst=self.dst, group=self.group, async_op=True)
+        else:
+            self.work[slot] = dist.gather(self.send[slot], gather_list=None, dst=self.dst,
+                                          group=self.group, async_op=True)
+
+    def drain(self):
+        for slot in range(self.depth):
+            if self.work[slot] is not None:
+                self.work[slot].wait()
+                self.work[slot] = None
+
+    def result(self, k):
+        slot = k % self.depth
+        if self.world == 1:
+            return self.send[slot].unsqueeze(0)
+        return self.recv[slot] if self.rank == self.dst else None
+
+
 def gather_ragged(shard, counts, dst=0, group=None):
     """Gather shards whose leading dimension differs per rank (counts[r] rows on
     rank r, known to every rank) with one grouped send/recv. Returns the
