@@ -291,6 +291,26 @@ def test_cartesian_paths_match_oracle(env, D, N, B):
         np.testing.assert_array_equal(hout[k][ok], out[k].cpu().numpy()[ok])
 
 
+def test_engine_reproduces_committed_regression_vectors(env, golden_dir):
+    """The oracle-generated vectors of tests/golden/solver_golden.npz, bit for bit."""
+    stored = dict(np.load(os.path.join(golden_dir, "solver_golden.npz")))
+    for name, rows, s0, s1, sd0, _meta in scenarios.all_cases():
+        out = _rows_solve(env, [rows], s0, s1, sd0)
+        assert out["status"][0] == stored["scn/%s/status" % name][0], name
+        assert out["last_extremal_index"][0] == stored["scn/%s/lei" % name][0], name
+        for k in ("time", "sd", "sdd"):
+            np.testing.assert_array_equal(out[k][0], stored["scn/%s/%s" % (name, k)], err_msg=name + k)
+    for D, N in ((7, 500), (7, 2000), (6, 2000), (14, 1000)):
+        key = "joint/D%d_N%d" % (D, N)
+        b = env["syn"].make_joint_batch(8, D, N)
+        _, out = solve_joint(env, b, N, D)
+        np.testing.assert_array_equal(out["status"].cpu().numpy(), stored[key + "/status"])
+        np.testing.assert_array_equal(out["last_extremal_index"].cpu().numpy(), stored[key + "/lei"])
+        for k in ("time", "sd", "sdd"):
+            np.testing.assert_array_equal(out[k].cpu().numpy(), stored[key + "/" + k], err_msg=key + k)
+        np.testing.assert_array_equal(out["qdd"].cpu().numpy()[:, :, -1], stored[key + "/qdd_last_joint"])
+
+
 def test_joint_mode_bad_limits_fail_per_path(env):
     syn = env["syn"]
     b = syn.make_joint_batch(6, 7, 300)

@@ -125,3 +125,22 @@ def test_end_padding_beyond_last_knot():
     r = tpo.time_joint_batch(knots[None], cps[None], np.array([[1.0, 1.0]]),
                              np.array([[2.0, 2.0]]), 0.0, delta, N)
     assert r["status"][0] in (0, 7, 8, 9, 10)   # must terminate with a reference outcome
+
+
+def test_oracle_reproduces_committed_regression_vectors(golden_dir):
+    """tests/golden/solver_golden.npz (tools/make_solver_golden.py): oracle-generated, hence a
+    regression pin of the oracle itself, not a parity pin against the reference."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "make_solver_golden", os.path.join(os.path.dirname(golden_dir.rstrip("/")), "..", "tools",
+                                           "make_solver_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stored = dict(np.load(os.path.join(golden_dir, "solver_golden.npz")))
+    sha = bytes(stored.pop("sha256")).decode()
+    assert mod.digest(stored) == sha, "fixture file corrupted"
+    now = mod.compute()
+    assert sorted(now) == sorted(stored)
+    for k in stored:
+        np.testing.assert_array_equal(now[k], stored[k], err_msg=k)
