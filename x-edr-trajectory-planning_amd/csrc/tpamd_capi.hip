@@ -244,6 +244,7 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
   const dim3 grid_s((N + 255) / 256, B);
   {
     Timer t(e, st, KI_DETECT);
+    hipLaunchKernelGGL((k_boundary_zfit<Source>), grid_s, dim3(256), 0, st, N, src, ws);
     hipLaunchKernelGGL(k_boundary_detect, grid_s, dim3(256), 0, st, N, ws);
   }
   {

@@ -529,6 +529,12 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   }
   return v;
 }
+// value of lane `src_lane`, which must be wave-uniform (v_readlane_b32)
+__device__ __forceinline__ double wave_bcast_const(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_bcast_f64(double v, int src_lane) {
   return __shfl(v, src_lane, 64);
 }

@@ -155,21 +155,16 @@ template <int WORDS, bool JOINT, class R>
 __device__ __forceinline__ void boundary_point(const R &r, int C, size_t o, Workspace ws) {
   double sd2max, sddmax, sd2zero;
   lp_find_max_sd2<WORDS>(r, C, &sd2max, &sddmax, &sd2zero);
-  double x0, y0, xz, yz;
+  double x0, y0;
   if (JOINT) find_sdd_both_joint(r, C / 2, sd2max, &x0, &y0);
   else find_sdd_both(r, C, sd2max, &x0, &y0);
-  if (sd2zero == sd2max) {
-    xz = x0; yz = y0;
-  } else {
-    if (JOINT) find_sdd_both_joint(r, C / 2, sd2zero, &xz, &yz);
-    else find_sdd_both(r, C, sd2zero, &xz, &yz);
-  }
   ws.m0[o] = sd2max;
   ws.z0[o] = sd2zero;
   ws.X0[o] = x0;
   ws.Y0[o] = y0;
-  ws.Xz[o] = xz;
-  ws.Yz[o] = yz;
+  // FindSddMax/Min at sd2_max_for_sdd0 (Xz, Yz) are needed only next to isolated points
+  // and deferred fixes (.cc:1386-1395, :1440-1447): k_boundary_zfit / k_boundary_final
+  // evaluate them there, as the reference does.
   ws.at0[o] = fabs(sd2max - sd2zero) < kTiny;
 }
 
@@ -495,18 +490,29 @@ __device__ __forceinline__ double final_m(const Workspace &ws, size_t pb, int N,
 template <class R>
 __device__ __forceinline__ void wave_find_sdd_both(const R &r, int C, double sd2, int lane,
                                                    double *sdd_max, double *sdd_min) {
+  // lane k < C keeps row k in registers (one parallel load phase); the validity loop then
+  // reads row k of every lane's candidate through readlane instead of re-loading it
+  const bool has = lane < C;
+  const double a_m = has ? r.a(lane) : 0.0, b_m = has ? r.b(lane) : 0.0;
+  const double lo_m = has ? r.lo(lane) : 0.0, hi_m = has ? r.hi(lane) : 0.0;
   double smax = -DBL_MAX, smin = DBL_MAX;
-  for (int c = lane; c < 2 * C; c += 64) {
-    const int i = c >> 1;
-    const double A = r.a(i);
-    if (!is_tiny(A)) {
-      const double bs = r.b(i) * sd2;
-      const double lim = (c & 1) ? r.hi(i) : r.lo(i);
-      const double sddi = (lim - bs) / A;
-      if ((sddi == sddi) && rows_valid(r, C, sddi, sd2)) {
-        if (sddi > smax) smax = sddi;
-        if (sddi < smin) smin = sddi;
-      }
+  for (int c0 = 0; c0 < 2 * C; c0 += 64) {
+    const int c = c0 + lane;
+    const int i = min(c >> 1, C - 1);
+    const double A = __shfl(a_m, i, 64);
+    const double bs = __shfl(b_m, i, 64) * sd2;
+    // both shuffles outside any lane-dependent branch: a shuffle reads only active lanes
+    const double hi_i = __shfl(hi_m, i, 64), lo_i = __shfl(lo_m, i, 64);
+    const double lim = (c & 1) ? hi_i : lo_i;
+    const double sddi = (lim - bs) / A;
+    bool bad = (c >= 2 * C) | is_tiny(A) | (sddi != sddi);
+    for (int k = 0; k < C; k++) {
+      const double v = wave_bcast_const(a_m, k) * sddi + wave_bcast_const(b_m, k) * sd2;
+      bad = bad | (v + kTiny < wave_bcast_const(lo_m, k)) | (v - kTiny > wave_bcast_const(hi_m, k));
+    }
+    if (!bad) {
+      if (sddi > smax) smax = sddi;
+      if (sddi < smin) smin = sddi;
     }
   }
   smax = wave_max_f64(smax);
@@ -517,15 +523,45 @@ __device__ __forceinline__ void wave_find_sdd_both(const R &r, int C, double sd2
   *sdd_min = smin;
 }
 
+// CalculateBoundary pass 2, first half (.cc:1386-1395): the two neighbours of an isolated
+// point take sd2_max_for_sdd0 as their boundary value and FindSddMax/Min there. Those are
+// the only places (besides the deferred fixes, see k_boundary_final) where Xz/Yz are read,
+// so they are evaluated here, one wave per such sample, instead of for every sample in K1.
+template <class Source>
+__global__ void __launch_bounds__(256) k_boundary_zfit(int stride, Source src, Workspace ws) {
+  __shared__ int s_count;
+  __shared__ int s_list[256];
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x * 256 + tid;
+  const int N = path_samples(ws, b, stride);
+  const size_t pb = (size_t)b * stride;
+  const uint8_t *at = ws.at0 + pb;
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+  if (j < N && (iso_at(at, N, j - 1) || iso_at(at, N, j + 1))) s_list[atomicAdd(&s_count, 1)] = tid;
+  __syncthreads();
+  const int count = s_count;
+  const int lane = tid & 63;
+  for (int it = tid >> 6; it < count; it += 4) {
+    const int jj = blockIdx.x * 256 + s_list[it];
+    const auto r = src.at(b, stride, jj);
+    double x, y;
+    wave_find_sdd_both(r, src.rows(), ws.z0[pb + jj], lane, &x, &y);
+    if (lane == 0) { ws.Xz[pb + jj] = x; ws.Yz[pb + jj] = y; }
+  }
+}
+
 // Block = 256 threads, one per sample. The few samples whose boundary value was replaced
-// in pass 3 need FindSddMax/Min at the new value; they are collected in LDS and each is
+// in pass 3 (by a new value, or by sd2_max_for_sdd0 next to a fix) need FindSddMax/Min
+// there; they are collected in LDS and each is
 // evaluated by a whole wave (the per-thread version made every wave holding one such
 // sample run the full candidate loop).
 template <class Source>
 __global__ void __launch_bounds__(256) k_boundary_final(int stride, Source src, Workspace ws) {
   __shared__ int s_count;
   __shared__ int s_list[256];
-  __shared__ double s_X[256], s_Y[256];
+  __shared__ double s_X[256], s_Y[256], s_at[256];
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
   const int j = blockIdx.x * 256 + tid;
@@ -543,17 +579,25 @@ __global__ void __launch_bounds__(256) k_boundary_final(int stride, Source src, 
     const bool f_self = ff[j];
     const bool f_prev = (j >= 1) && ff[j - 1];
     if (f_next || (!f_self && f_prev)) {
-      m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
+      m = ws.z0[pb + j];
+      if (iso_at(at, N, j - 1) || iso_at(at, N, j + 1)) {   // k_boundary_zfit was here
+        X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
+      } else {
+        refit = true;
+      }
     } else if (f_self) {
       m = ws.fix_val[pb + j];
       refit = true;
-      s_list[atomicAdd(&s_count, 1)] = tid;
     } else if (iso_at(at, N, j + 1)) {
       m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Yz[pb + j];
     } else if (iso_at(at, N, j - 1)) {
       m = ws.z0[pb + j]; X = ws.Xz[pb + j]; Y = ws.Xz[pb + j];  // sic, .cc:1394-1395
     } else {
       m = ws.m0[pb + j]; X = ws.X0[pb + j]; Y = ws.Y0[pb + j];
+    }
+    if (refit) {
+      s_list[atomicAdd(&s_count, 1)] = tid;
+      s_at[tid] = m;
     }
   }
   __syncthreads();
@@ -565,7 +609,7 @@ __global__ void __launch_bounds__(256) k_boundary_final(int stride, Source src, 
       const int jj = blockIdx.x * 256 + t;
       const auto r = src.at(b, stride, jj);
       double x, y;
-      wave_find_sdd_both(r, src.rows(), ws.fix_val[pb + jj], lane, &x, &y);
+      wave_find_sdd_both(r, src.rows(), s_at[t], lane, &x, &y);
       if (lane == 0) { s_X[t] = x; s_Y[t] = y; }
     }
   }
