@@ -178,7 +178,10 @@ void allow_big_lds(K kernel) {
 void configure_kernels_once() {
   if (lds_limit_set) return;
   lds_limit_set = 1;
-  allow_big_lds(k_sample_lp_joint<1>);
+  allow_big_lds(k_sample_lp_joint<1, 0>);
+  allow_big_lds(k_sample_lp_joint<1, 6>);
+  allow_big_lds(k_sample_lp_joint<1, 7>);
+  allow_big_lds(k_sample_lp_joint<1, 14>);
   allow_big_lds(k_lp_rows<1>);
   allow_big_lds(k_lp_rows<2>);
   allow_big_lds(k_sweep<JointSource>);
@@ -377,8 +380,15 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
     const int tpb = (C <= 28) ? 256 : 128;
     const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)D * tpb) * 8;
     if (lds > 160 * 1024) return TPAMD_E_UNSUPPORTED;
-    hipLaunchKernelGGL((k_sample_lp_joint<1>), dim3((N + tpb - 1) / tpb, B), dim3(tpb), lds, st,
-                       N, D, P, in->knots, in->control_points, out->q, ws);
+    const dim3 grid((N + tpb - 1) / tpb, B);
+#define TPAMD_K1(DD)                                                                         \
+  hipLaunchKernelGGL((k_sample_lp_joint<1, DD>), grid, dim3(tpb), lds, st, N, D, P, in->knots, \
+                     in->control_points, out->q, ws)
+    if (D == 7 && !e->force_generic) TPAMD_K1(7);
+    else if (D == 6 && !e->force_generic) TPAMD_K1(6);
+    else if (D == 14 && !e->force_generic) TPAMD_K1(14);
+    else TPAMD_K1(0);
+#undef TPAMD_K1
   }
   JointSource src;
   src.q12 = ws.q12; src.lim = ws.lim; src.D = D;

@@ -186,6 +186,57 @@ __device__ void find_sdd_both_joint(const R &r, int D, double sd2, double *sdd_m
   *sdd_min = smin;
 }
 
+// find_sdd_both_joint with the joint count known at compile time: q' (a) and q'' (b) of
+// the sample live in registers, b*sd2 is formed once per row, every loop is unrolled and
+// the row checks are branch-free. Same operations per candidate and per row check as
+// find_sdd_both_joint, hence the same bits. hi[0..D) are the acceleration bounds (their
+// lower bounds are -hi, timeable_path_joint_spline.cc:327-330), hi[D..2D) the velocity
+// bounds (lower 0).
+template <int D>
+__device__ __forceinline__ void find_sdd_both_joint_fixed(const double (&a)[D], const double (&b)[D],
+                                                          const double *lim_hi, double sd2,
+                                                          double *sdd_max, double *sdd_min) {
+  double smax = -DBL_MAX, smin = DBL_MAX;
+  bool vel_ok = true;
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    const double v = (a[j] * a[j]) * sd2;
+    if (v + kTiny < 0.0 || v - kTiny > lim_hi[D + j]) vel_ok = false;
+  }
+  if (vel_ok) {
+    double bs[D], hi[D];
+#pragma unroll
+    for (int j = 0; j < D; j++) { bs[j] = b[j] * sd2; hi[j] = lim_hi[j]; }
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      const double A = a[i];
+      if (!is_tiny(A)) {
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+          const double lim = w ? hi[i] : -hi[i];
+          const double sddi = (lim - bs[i]) / A;
+          if ((fabs(sddi) <= DBL_MAX) && ((sddi > smax) || (sddi < smin))) {
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < D; j++) {
+              const double v = a[j] * sddi + bs[j];
+              bad = bad | (v + kTiny < -hi[j]) | (v - kTiny > hi[j]);
+            }
+            if (!bad) {
+              if (sddi > smax) smax = sddi;
+              if (sddi < smin) smin = sddi;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (smax == -DBL_MAX) smax = 0;
+  if (smin == DBL_MAX) smin = 0;
+  *sdd_max = smax;
+  *sdd_min = smin;
+}
+
 // ---------------------------------------------------------------------------
 // 2-variable LP: FindMaxSd2Simplex, time_optimal_path_timing.cc:1149-1363, with
 // IsOptimal :1105-1147. The reference's constraint_set_ / active_set_ vectors

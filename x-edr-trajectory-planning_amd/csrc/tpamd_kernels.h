@@ -174,15 +174,19 @@ __device__ __forceinline__ void boundary_point(const R &r, int C, size_t o, Work
 // SamplePath: timeable_path_joint_spline.cc:294-318; EvalCurveAndDerivatives:
 // splines/bspline.h:540-568; ConstraintSetup: timeable_path_joint_spline.cc:320-343;
 // CalculateBoundary pass 1: time_optimal_path_timing.cc:1366-1377.
-template <int WORDS>
-__global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
+// DT > 0: joint count fixed at compile time (q', q'' of the thread's sample also stay in
+// registers for FindSddMax/Min); DT = 0: any D.
+template <int WORDS, int DT>
+__global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
                                   const double *cps_g, double *q_out, Workspace ws) {
   extern __shared__ double lds[];
   const int TPB = blockDim.x;
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int K = P + 3;
+  const int D = DT ? DT : D_rt;
   const int C = 2 * D;
+  double q1r[DT ? DT : 1], q2r[DT ? DT : 1];
   double *s_knots = lds;
   double *s_cp = s_knots + K;
   double *s_lo = s_cp + P * D;
@@ -211,6 +215,7 @@ __global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
     double ders[3][3];
     basis_ders_deg2(s_knots, span, u, ders);
     const double *p0 = s_cp + (size_t)(span - 2) * D, *p1 = p0 + D, *p2 = p1 + D;
+#pragma unroll
     for (int d = 0; d < D; d++) {
       double v0 = 0.0, v1 = 0.0, v2 = 0.0;
       v0 += ders[0][0] * p0[d]; v0 += ders[0][1] * p1[d]; v0 += ders[0][2] * p2[d];
@@ -220,19 +225,33 @@ __global__ void k_sample_lp_joint(int N, int D, int P, const double *knots_g,
       *reinterpret_cast<double2 *>(q12 + 2 * d) = make_double2(v1, v2);
       Q1[d * TPB] = v1;
       Q2[d * TPB] = v2;
+      if (DT) { q1r[d] = v1; q2r[d] = v2; }
     }
   } else {
     const double *pl = s_cp + (size_t)(P - 1) * D;
+#pragma unroll
     for (int d = 0; d < D; d++) {
       if (q_out) q_out[o * D + d] = pl[d];
       *reinterpret_cast<double2 *>(q12 + 2 * d) = make_double2(0.0, 0.0);
       Q1[d * TPB] = 0.0;
       Q2[d * TPB] = 0.0;
+      if (DT) { q1r[d] = 0.0; q2r[d] = 0.0; }
     }
   }
   LdsRowsJoint r;
   r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
-  boundary_point<WORDS, true>(r, C, o, ws);
+  if (DT) {
+    double sd2max, sddmax, sd2zero, x0, y0;
+    lp_find_max_sd2<WORDS>(r, C, &sd2max, &sddmax, &sd2zero);
+    find_sdd_both_joint_fixed<(DT ? DT : 1)>(q1r, q2r, s_hi, sd2max, &x0, &y0);
+    ws.m0[o] = sd2max;
+    ws.z0[o] = sd2zero;
+    ws.X0[o] = x0;
+    ws.Y0[o] = y0;
+    ws.at0[o] = fabs(sd2max - sd2zero) < kTiny;
+  } else {
+    boundary_point<WORDS, true>(r, C, o, ws);
+  }
 }
 
 // Sampling only (TimeableJointSplinePath::SamplePath as a stand-alone call,
