@@ -196,17 +196,19 @@ void configure_kernels_once() {
 
 // The sweep launch: joint-space batches with D in {6, 7, 14} (the BASELINE.json
 // configurations) take the specialised kernel, everything else the generic one.
+// Returns true if the kernel also wrote qd/qdd (the planner epilogue).
 template <class Source>
-void launch_sweep(hipStream_t st, int B, int N, int max_loops, const Source &src,
+bool launch_sweep(hipStream_t st, int B, int N, int max_loops, const Source &src,
                   const Workspace &ws, const tpamd_path_outputs *out, bool force_generic) {
   const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
   hipLaunchKernelGGL((k_sweep<Source>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
                      out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
                      out->max_time_increment, out->status);
+  return false;
 }
 
 template <>
-void launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
+bool launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
                                const Workspace &ws, const tpamd_path_outputs *out,
                                bool force_generic) {
   const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
@@ -222,26 +224,28 @@ void launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, cons
       hipLaunchKernelGGL((k_sweep_joint<DD, 2>), dim3(B), dim3(128),                             \
                          sweep_joint_lds_bytes<DD>(N, 2), st, N, max_loops, src, ws, out->time,  \
                          out->s, out->sd, out->sdd, out->last_extremal_index,                    \
-                         out->max_time_increment, out->status);                                  \
+                         out->max_time_increment, out->status, out->qd, out->qdd);               \
     else                                                                                         \
       hipLaunchKernelGGL((k_sweep_joint<DD, 1>), dim3(B), dim3(64),                              \
                          sweep_joint_lds_bytes<DD>(N, 1), st, N, max_loops, src, ws, out->time,  \
                          out->s, out->sd, out->sdd, out->last_extremal_index,                    \
-                         out->max_time_increment, out->status);                                  \
+                         out->max_time_increment, out->status, out->qd, out->qdd);               \
   } while (0)
-  if (!force_generic && src.D == 7) { TPAMD_LAUNCH_JOINT(7); return; }
-  if (!force_generic && src.D == 6) { TPAMD_LAUNCH_JOINT(6); return; }
-  if (!force_generic && src.D == 14) { TPAMD_LAUNCH_JOINT(14); return; }
+  if (!force_generic && src.D == 7) { TPAMD_LAUNCH_JOINT(7); return true; }
+  if (!force_generic && src.D == 6) { TPAMD_LAUNCH_JOINT(6); return true; }
+  if (!force_generic && src.D == 14) { TPAMD_LAUNCH_JOINT(14); return true; }
 #undef TPAMD_LAUNCH_JOINT
   hipLaunchKernelGGL((k_sweep<JointSource>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
                      out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
                      out->max_time_increment, out->status);
+  return false;
 }
 
 // Shared tail: detect -> final -> sweep (-> epilogue in joint mode).
 template <class Source>
 int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int max_loops,
-                           const Source &src, const tpamd_path_outputs *out) {
+                           const Source &src, const tpamd_path_outputs *out,
+                           bool *epilogue_done = nullptr) {
   e->ws.sd2_out = out->sd2;
   const Workspace &ws = e->ws;
   const dim3 grid_s((N + 255) / 256, B);
@@ -256,7 +260,8 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
   }
   {
     Timer t(e, st, KI_SWEEP);
-    launch_sweep(st, B, N, max_loops, src, ws, out, e->force_generic);
+    const bool fused = launch_sweep(st, B, N, max_loops, src, ws, out, e->force_generic);
+    if (epilogue_done) *epilogue_done = fused;
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -366,6 +371,7 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   if (rc) return rc;
   e->last_B = B; e->last_N = N;
   e->ws.ns = in->num_samples_per_path;
+  e->ws.amax = in->max_acceleration;
   const Workspace &ws = e->ws;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;  // 0: per path, max(100, 10 n)
   {
@@ -392,9 +398,10 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   }
   JointSource src;
   src.q12 = ws.q12; src.lim = ws.lim; src.D = D;
-  rc = run_boundary_and_sweep(e, st, B, N, max_loops, src, out);
+  bool fused = false;
+  rc = run_boundary_and_sweep(e, st, B, N, max_loops, src, out, &fused);
   if (rc) return rc;
-  if (out->qd || out->qdd) {
+  if (!fused && (out->qd || out->qdd)) {   // the specialised sweep kernels write qd/qdd themselves
     Timer t(e, st, KI_EPILOGUE);
     const size_t total = (size_t)B * N * D;
     hipLaunchKernelGGL(k_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, N,

@@ -25,6 +25,7 @@ struct Workspace {
   // Ragged batches: number of samples of each path (null: every path has N samples).
   // Arrays keep the common stride N; only the first ns[b] samples of path b are used.
   const int32_t *ns;
+  const double *amax;          // [B][D] joint acceleration limits (fused epilogue), or null
   double *lim;  // [B][2][C] lower then upper (joint mode)
   // per (path, sample)
   // joint mode: one record of R = 2D+2 doubles per sample,
@@ -868,8 +869,16 @@ __device__ __forceinline__ double wave_ordered_prefix(double d, double carry) {
 // null, is an LDS bitmap of samples whose sdd entry still holds the numerator
 // 0.5*(sd2[i+-1] - sd2[i]) of a boundary-following step: the division by ds that the
 // reference performs at .cc:787/:877 is done here, off the sequential chain.
+// The tail is run by ONE wave (the whole block in the generic kernel, wave 0 in the two-wave
+// kernel): stores of some lanes must be visible to loads of others, nothing more.
+__device__ __forceinline__ void tail_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Returns the path's final status.
 template <class Source>
-__device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &ws, int b, int N, int stride,
+__device__ __forceinline__ int sweep_tail(const Source &src, const Workspace &ws, int b, int N, int stride,
                            int lane, int status, double *sd2, double *sdd, const uint32_t *pend,
                            bool copy_sdd, double *t_out, double *s_out, double *sd_out,
                            double *sdd_out, int32_t *lei_out, double *dtmax_out,
@@ -881,7 +890,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
   if (pend) {
     for (int idx = lane; idx < N; idx += 64)
       if (pend[idx >> 5] & (1u << (idx & 31))) sdd[idx] = sdd[idx] / ds;
-    __syncthreads();
+    tail_sync();
   }
   // NaN check and sdd fill-in (.cc:398-411); every index is independent.
   if (status == 0) {
@@ -914,7 +923,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
         sdd[idx] = res;
       }
     }
-    __syncthreads();
+    tail_sync();
     // Enforce the start acceleration if admissible (.cc:413-416): rows over lanes.
     {
       const double sdd_start = ws.sdd_start[b];
@@ -927,7 +936,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
       }
       if (!__any(bad) && lane == 0) sdd[0] = sdd_start;
     }
-    __syncthreads();
+    tail_sync();
     if (sd2[N - 1] != 0) status = 9;
   }
   if (status != 0) {
@@ -936,7 +945,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
       if (lei_out) lei_out[b] = 0;
       if (dtmax_out) dtmax_out[b] = -1.0;
     }
-    return;
+    return status;
   }
 
   // last_extremal_index_ (.cc:430-445): scan down from N-2 for sdd > 0 or a
@@ -988,7 +997,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
   }
   dtmax = wave_max_f64(dtmax);
   if (copy_sdd) {
-    __syncthreads();
+    tail_sync();
     for (int idx = lane; idx < N; idx += 64) sdd_out[pb + idx] = sdd[idx];
   }
   if (lane == 0) {
@@ -996,6 +1005,7 @@ __device__ __forceinline__ void sweep_tail(const Source &src, const Workspace &w
     if (lei_out) lei_out[b] = lei;
     if (dtmax_out) dtmax_out[b] = dtmax;
   }
+  return 0;
 }
 
 // Dynamic LDS: sd2[N] | sdd[N] | dt[64]

@@ -776,7 +776,7 @@ template <int D, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES)
 k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
               double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
-              int32_t *status_out) {
+              int32_t *status_out, double *qd_out, double *qdd_out) {
   extern __shared__ double lds[];
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63;
@@ -963,18 +963,66 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     for (int k = 0; k < 16; k++)
       if (WAVES == 1 || k == 0 || k >= 8) ws.diag[(size_t)b * 16 + k] = S.diag[k];
 #endif
-  if (w != 0) return;
-  {
+  int fstatus = 0;
+  if (w == 0) {
     TPAMD_T0(t0);
-    sweep_tail(src, ws, b, N, stride, lane, status, sd2, S.sdd_g, nullptr, /*copy_sdd=*/false, t_out, s_out,
-               sd_out, sdd_out, lei_out, dtmax_out, status_out);
+    fstatus = sweep_tail(src, ws, b, N, stride, lane, status, sd2, S.sdd_g, nullptr, /*copy_sdd=*/false, t_out,
+                         s_out, sd_out, sdd_out, lei_out, dtmax_out, status_out);
     TPAMD_ACC(3, t0);
   }
 #ifdef TPAMD_DIAG
-  if (lane == 0 && ws.diag)
+  if (w == 0 && lane == 0 && ws.diag)
     for (int k = 0; k < 16; k++)
       if (WAVES == 1 || (k != 0 && k < 8)) ws.diag[(size_t)b * 16 + k] = S.diag[k];
 #endif
+  // Planner epilogue (path_timing_trajectory.cc:458-472) by all lanes of the block:
+  // qd = q' sd, qdd = clamp(q' sdd + q'' sd^2, +-a_max). sd and sdd are read back from the
+  // output rows the tail has just written.
+  if (qd_out == nullptr && qdd_out == nullptr) return;
+  if (WAVES == 2) {
+    if (w == 0 && lane == 0) xchg[0] = fstatus;
+    __threadfence_block();
+    __syncthreads();
+    fstatus = uniform_i32(xchg[0]);
+  } else {
+    tail_sync();
+  }
+  if (fstatus != 0) return;
+  {
+    const double *am_g = ws.amax + (size_t)b * D;
+    const f64x2 *rec2 = reinterpret_cast<const f64x2 *>(S.rec);
+    const int total = N * D;
+    constexpr int kBatch = 16;   // loads in flight per lane (the loop is latency-bound otherwise)
+    constexpr int kStep = 64 * WAVES;
+    for (int e0 = tid; e0 < total; e0 += kStep * kBatch) {
+      f64x2 pr[kBatch];
+      double v[kBatch], a[kBatch], am[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; u++) {
+        const int e = min(e0 + u * kStep, total - 1);
+        const int i = e / D;
+        const int d = e - i * D;
+        pr[u] = rec2[(size_t)i * (JS::R / 2) + d];
+        v[u] = sd_out[pb + i];
+        a[u] = sdd_out[pb + i];
+        am[u] = am_g[d];
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; u++) {
+        const int e = e0 + u * kStep;
+        if (e < total) {
+          if (qd_out) qd_out[pb * D + e] = pr[u].x * v[u];
+          if (qdd_out) {
+            const double v2 = v[u] * v[u];
+            double acc = pr[u].x * a[u] + pr[u].y * v2;
+            if (acc < -am[u]) acc = -am[u];
+            if (acc > am[u]) acc = am[u];
+            qdd_out[pb * D + e] = acc;
+          }
+        }
+      }
+    }
+  }
 }
 
 }  // namespace tpamd
