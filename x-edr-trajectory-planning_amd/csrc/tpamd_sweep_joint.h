@@ -622,7 +622,12 @@ struct JointSweep {
   // afterwards the two extremals work on disjoint index ranges.
   // The scalar loop is unrolled by two so that the two row sets swap roles without copies.
   template <bool FWD>
-  __device__ __forceinline__ int add_extremal(int idx_start, bool pair_signal = false) {
+  // `pf`: tile prefetch registers, possibly already holding the start tile (see the kernel).
+  // wait_pair (two-wave kernel, forward extremal only): the partner's release barrier is
+  // taken after this extremal's own set-up (tile fill, row loads), which touches nothing the
+  // partner's first step writes.
+  __device__ __forceinline__ int add_extremal(int idx_start, Prefetch &pf, bool pair_signal = false,
+                                              bool wait_pair = false) {
     constexpr int dir = FWD ? 1 : -1;
 #define TPAMD_PAIR_SIGNAL()                                   \
   do {                                                        \
@@ -634,13 +639,13 @@ struct JointSweep {
   } while (0)
     if (FWD ? !(idx_start < N - 2) : !(idx_start > 1)) {
       TPAMD_PAIR_SIGNAL();
+      if (wait_pair) __syncthreads();
       return FWD ? N - 1 : 0;
     }
     Rows rows_a, rows_b;
-    Prefetch pf;
-    pf.tag = -1;
     Carry c;
     init_carry<FWD>(idx_start, c, rows_a, pf, true);
+    if (wait_pair) __syncthreads();
     bool trust = true;
     int last_win = -1;
     for (;;) {
@@ -866,6 +871,8 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 
   int status = 0;
   int iforw_lo = 0, iback_hi = N - 1, iback_lo, iforw_hi, icrit, icrit_lo, icrit_hi;
+  typename JS::Prefetch pf;
+  pf.tag = -1;
 #ifdef TPAMD_DIAG
   long long(&diag)[16] = S.diag;
   for (int k = 0; k < 16; k++) diag[k] = 0;
@@ -874,17 +881,17 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   // First pair: the forward extremal from 0 may run into the backward one from N-1, so the
   // two are sequential (time_optimal_path_timing.cc:325-326).
   if (WAVES == 1) {
-    iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi));
-    iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo));
+    iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi, pf));
+    iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo, pf));
   } else {
     if (w == 0) {
-      const int r = S.template add_extremal<false>(iback_hi);
+      const int r = S.template add_extremal<false>(iback_hi, pf);
       if (lane == 0) xchg[0] = r;
     }
     __threadfence_block();
     __syncthreads();
     if (w == 1) {
-      const int r = S.template add_extremal<true>(iforw_lo);
+      const int r = S.template add_extremal<true>(iforw_lo, pf);
       if (lane == 0) xchg[1] = r;
     }
     __threadfence_block();
@@ -892,6 +899,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     iback_lo = uniform_i32(xchg[0]);
     iforw_hi = uniform_i32(xchg[1]);
   }
+  TPAMD_ACC(9, t_all);   // first pair (sequential)
   icrit_hi = iback_lo;
   if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
     if (w == 0) S.put_sd2(icrit_hi, qnan());
@@ -911,6 +919,13 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
       TPAMD_ACC(2, t0);
     }
     if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
+    if (icrit >= 1) {
+      // the tile this wave's extremal starts in: its loads fly together with the loads of
+      // the boundary values below instead of after them
+      const int ts = ((WAVES == 2 && w == 1) ? icrit : icrit - 1) / kTileSamples;
+      const int tag = (ts & 1) ? S.tag1 : S.tag0;
+      if (tag != ts && pf.tag != ts) S.issue_tile_loads(ts, pf);
+    }
     if (WAVES == 2) __syncthreads();   // both waves finished reading sd2 before the marks below
     if (icrit > 0 && icrit < N - 1 && w == 0) S.put_sd2(icrit, m_g[icrit]);
     if (icrit < 1) { status = 10; break; }
@@ -924,25 +939,24 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     if (WAVES == 1) {
       {
         TPAMD_T0(t0);
-        iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi));
+        iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi, pf));
         TPAMD_ACC(1, t0);
       }
       {
         TPAMD_T0(t0);
-        iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo));
+        iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo, pf));
         TPAMD_ACC(0, t0);
       }
     } else {
       __syncthreads();                 // A: the marks are visible to the forward wave
       if (w == 0) {
         TPAMD_T0(t0);
-        const int r = S.template add_extremal<false>(iback_hi, /*pair_signal=*/true);   // B inside
+        const int r = S.template add_extremal<false>(iback_hi, pf, /*pair_signal=*/true);   // B inside
         if (lane == 0) xchg[0] = r;
         TPAMD_ACC(1, t0);
       } else {
-        __syncthreads();               // B: the backward extremal's first step is done
         TPAMD_T0(t0);
-        const int r = S.template add_extremal<true>(iforw_lo);
+        const int r = S.template add_extremal<true>(iforw_lo, pf, false, /*wait_pair=*/true);   // B inside
         if (lane == 0) xchg[1] = r;
         TPAMD_ACC(0, t0);
       }
