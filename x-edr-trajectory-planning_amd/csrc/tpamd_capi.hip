@@ -192,6 +192,10 @@ void configure_kernels_once() {
   allow_big_lds(k_sweep_joint<6, 2>);
   allow_big_lds(k_sweep_joint<7, 2>);
   allow_big_lds(k_sweep_joint<14, 2>);
+  allow_big_lds(k_sweep_joint<6, 2, 2>);
+  allow_big_lds(k_sweep_joint<7, 2, 2>);
+  allow_big_lds(k_cartesian_lp<1, 6>);
+  allow_big_lds(k_cartesian_lp<1, 7>);
 }
 
 // The sweep launch: joint-space batches with D in {6, 7, 14} (the BASELINE.json
@@ -265,6 +269,16 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
   }
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// Cartesian batches with D in {6, 7}: records carry two extra B-only rows.
+template <int DD>
+void launch_sweep_cartesian(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
+                            const Workspace &ws, const tpamd_path_outputs *out) {
+  hipLaunchKernelGGL((k_sweep_joint<DD, 2, 2>), dim3(B), dim3(128),
+                     (sweep_joint_lds_bytes<DD, 2>(N, 2)), st, N, max_loops, src, ws, out->time,
+                     out->s, out->sd, out->sdd, out->last_extremal_index,
+                     out->max_time_increment, out->status, out->qd, out->qdd);
 }
 
 // LP boundary points of explicit rows, then the shared tail.
@@ -454,22 +468,69 @@ int tpamd_time_cartesian_paths_device(tpamd_engine *e, const tpamd_cartesian_bat
   HIPCHK(hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)hip_stream;
   const int C = 2 * D + 2;
-  int rc = ensure_workspace(e, B, N, 2 * D);
-  if (rc) return rc;
-  const size_t nrow = align_up((size_t)B * N * C * 8, 256);
-  rc = ensure_rows(e, 4 * nrow);
+  const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;
+  const bool fused = (D == 6 || D == 7) && !e->force_generic;
+  int rc = ensure_workspace(e, B, N, C);
   if (rc) return rc;
   e->last_B = B; e->last_N = N;
   e->ws.ns = nullptr;
+  e->ws.amax = in->max_acceleration;
+  {
+    Timer t(e, st, KI_SETUP);
+    hipLaunchKernelGGL(k_setup_cartesian, dim3((B + 127) / 128), dim3(128), 0, st, B, N, D,
+                       bt->constraint_safety, in->max_velocity, in->max_acceleration,
+                       in->max_translational_velocity, in->max_rotational_velocity,
+                       in->path_start, in->delta, in->sd_start, in->sdd_start, in->time_start,
+                       e->ws);
+  }
+  if (fused) {
+    // rows never materialised: K1 writes records, the joint-structured kernels do the rest
+    const Workspace &ws = e->ws;
+    {
+      Timer t(e, st, KI_SAMPLE_LP);
+      const int tpb = 256;
+      const size_t lds = (2 * (size_t)C + (2 * (size_t)D + 2) * tpb) * 8;
+      const dim3 grid((N + tpb - 1) / tpb, B);
+      if (D == 6)
+        hipLaunchKernelGGL((k_cartesian_lp<1, 6>), grid, dim3(tpb), lds, st, N, in->ik_positions,
+                           in->jacobians, ws);
+      else
+        hipLaunchKernelGGL((k_cartesian_lp<1, 7>), grid, dim3(tpb), lds, st, N, in->ik_positions,
+                           in->jacobians, ws);
+    }
+    JointSource src;
+    src.q12 = ws.q12; src.lim = ws.lim; src.D = D; src.E = 2;
+    e->ws.sd2_out = out->sd2;
+    const dim3 grid_s((N + 255) / 256, B);
+    {
+      Timer t(e, st, KI_DETECT);
+      hipLaunchKernelGGL((k_boundary_zfit<JointSource>), grid_s, dim3(256), 0, st, N, src, e->ws);
+      hipLaunchKernelGGL(k_boundary_detect, grid_s, dim3(256), 0, st, N, e->ws);
+    }
+    {
+      Timer t(e, st, KI_FINAL);
+      hipLaunchKernelGGL((k_boundary_final<JointSource>), grid_s, dim3(256), 0, st, N, src, e->ws);
+    }
+    {
+      Timer t(e, st, KI_SWEEP);
+      if (D == 6) launch_sweep_cartesian<6>(st, B, N, max_loops, src, e->ws, out);
+      else launch_sweep_cartesian<7>(st, B, N, max_loops, src, e->ws, out);
+    }
+    if (out->q)
+      HIPCHK(hipMemcpyAsync(out->q, in->ik_positions, (size_t)B * N * D * 8,
+                            hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  const size_t nrow = align_up((size_t)B * N * C * 8, 256);
+  rc = ensure_rows(e, 4 * nrow);
+  if (rc) return rc;
   const Workspace &ws = e->ws;
   double *A = (double *)e->rows_base, *Bm = (double *)((char *)e->rows_base + nrow),
          *LO = (double *)((char *)e->rows_base + 2 * nrow),
          *HI = (double *)((char *)e->rows_base + 3 * nrow);
-  const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;
   {
     Timer t(e, st, KI_SETUP);
-    hipLaunchKernelGGL(k_setup_cartesian, dim3((B + 127) / 128), dim3(128), 0, st, B, N,
-                       in->path_start, in->delta, in->sd_start, in->sdd_start, in->time_start, ws);
     hipLaunchKernelGGL(k_cartesian_rows, dim3((N + 127) / 128, B), dim3(128), 0, st, N, D,
                        bt->constraint_safety, in->ik_positions, in->jacobians, in->max_velocity,
                        in->max_acceleration, in->max_translational_velocity,

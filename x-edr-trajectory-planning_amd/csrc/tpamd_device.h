@@ -65,11 +65,14 @@ struct LdsRows {
 // per-path limits are shared by the block.
 struct LdsRowsJoint {
   const double *Q1, *Q2;          // already offset by the thread index
-  const double *lim_lo, *lim_hi;  // [2D]
+  const double *lim_lo, *lim_hi;  // [2D + E]
   int stride, D;
+  int E = 0;                      // extra rows with A = 0 and an explicit B (Cartesian paths)
+  const double *X = nullptr;      // their B values, [E][stride], offset by the thread index
   __device__ __forceinline__ double a(int c) const { return c < D ? Q1[c * stride] : 0.0; }
   __device__ __forceinline__ double b(int c) const {
     if (c < D) return Q2[c * stride];
+    if (c >= 2 * D) return X[(c - 2 * D) * stride];
     const double v = Q1[(c - D) * stride];
     return v * v;
   }
@@ -80,14 +83,18 @@ struct LdsRowsJoint {
 // Rows of a joint-space sample computed on the fly from q' and q'' in global
 // memory (timeable_path_joint_spline.cc:320-343): rows 0..D-1 are the
 // acceleration rows (A = q', B = q''), rows D..2D-1 the velocity rows
-// (A = 0, B = q'^2). lim_lo / lim_hi are the per-path limits [2D].
+// (A = 0, B = q'^2). Cartesian paths (timeable_path_cartesian_spline.cc:578-592) append
+// E = 2 rows with A = 0 and B = |(J q')_{1..3}|^2, |(J q')_{4..6}|^2, stored after the
+// pairs. lim_lo / lim_hi are the per-path limits [2D + E].
 struct JointRowsAt {
-  const double *q12;  // &q12[sample][0]: interleaved pairs (q'[d], q''[d]), d = 0..D-1
+  const double *q12;  // &record[sample][0]: pairs (q'[d], q''[d]), d = 0..D-1, then E extras
   const double *lim_lo, *lim_hi;
   int D;
+  int E = 0;
   __device__ __forceinline__ double a(int c) const { return c < D ? q12[2 * c] : 0.0; }
   __device__ __forceinline__ double b(int c) const {
     if (c < D) return q12[2 * c + 1];
+    if (c >= 2 * D) return q12[c];      // extras sit at doubles 2D .. 2D+E-1 of the record
     const double v = q12[2 * (c - D)];
     return v * v;
   }

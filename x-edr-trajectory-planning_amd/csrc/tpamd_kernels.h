@@ -49,24 +49,26 @@ __device__ __forceinline__ int path_samples(const Workspace &ws, int b, int N) {
 }
 
 struct JointSource {
-  const double *q12;  // [B][N][2D+2] records
-  const double *lim;  // [B][2][2D]
+  const double *q12;  // [B][N][2D+E+2] records
+  const double *lim;  // [B][2][2D+E]
   int D;
-  __device__ __forceinline__ int rows() const { return 2 * D; }
+  int E = 0;          // extra B-only rows (Cartesian paths: 2)
+  __device__ __forceinline__ int rows() const { return 2 * D + E; }
   static constexpr bool kJoint = true;
-  __device__ __forceinline__ int stride() const { return 2 * D + 2; }
+  __device__ __forceinline__ int stride() const { return 2 * D + E + 2; }
   // final boundary value and classification into the sample's record
   __device__ __forceinline__ void put_record(int b, int N, int idx, double m, uint8_t type) const {
-    double *rec = const_cast<double *>(q12) + ((size_t)b * N + idx) * (2 * D + 2) + 2 * D;
+    double *rec = const_cast<double *>(q12) + ((size_t)b * N + idx) * stride() + 2 * D + E;
     rec[0] = m;
     rec[1] = __longlong_as_double((long long)type);
   }
   __device__ __forceinline__ JointRowsAt at(int b, int N, int idx) const {
     JointRowsAt r;
-    r.q12 = q12 + ((size_t)b * N + idx) * (2 * D + 2);
-    r.lim_lo = lim + (size_t)b * 4 * D;
-    r.lim_hi = r.lim_lo + 2 * D;
+    r.q12 = q12 + ((size_t)b * N + idx) * stride();
+    r.lim_lo = lim + (size_t)b * 2 * rows();
+    r.lim_hi = r.lim_lo + rows();
     r.D = D;
+    r.E = E;
     return r;
   }
 };
@@ -347,17 +349,41 @@ __global__ void k_cartesian_rows(int N, int D, double safety, const double *q_g,
 }
 
 // Setup for Cartesian paths: s_end = path_start + delta (N-1) as
-// path_timing_trajectory.cc:340-341; the per-sample checks are OR-ed in by k_lp_rows.
-__global__ void k_setup_cartesian(int B, int N, const double *path_start, const double *delta,
+// path_timing_trajectory.cc:340-341; the limit rows of
+// timeable_path_cartesian_spline.cc:559-592 (C = 2D+2 per path, constant along the path) and
+// the SetupProblem / IsSetupValid checks on them (time_optimal_path_timing.cc:174-175, :557).
+__global__ void k_setup_cartesian(int B, int N, int D, double safety, const double *vmax,
+                                  const double *amax, const double *vtrans, const double *vrot,
+                                  const double *path_start, const double *delta,
                                   const double *sd_start, const double *sdd_start,
                                   const double *t_start, Workspace ws) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  const int C = 2 * D + 2;
+  double *lo = ws.lim + (size_t)b * 2 * C, *hi = lo + C;
+  for (int d = 0; d < D; d++) {
+    const double am = amax[(size_t)b * D + d] * safety;
+    const double vm = vmax[(size_t)b * D + d] * safety;
+    hi[d] = am;          lo[d] = -am;
+    hi[D + d] = vm * vm; lo[D + d] = 0.0;
+  }
+  const double vt = vtrans[b], vr = vrot[b];
+  hi[2 * D] = vt * vt;     lo[2 * D] = -(vt * vt);
+  hi[2 * D + 1] = vr * vr; lo[2 * D + 1] = -(vr * vr);
+  double maxw = -DBL_MAX;
+  bool lower_ge_upper = false;
+  for (int c = 0; c < C; c++) {
+    const double w = hi[c] - lo[c];
+    if (w > maxw) maxw = w;
+    if (lo[c] >= hi[c]) lower_ge_upper = true;
+  }
   const double s0 = path_start[b];
   const double s1 = s0 + delta[b] * (N - 1);
   uint32_t bits = 0;
+  if (maxw <= 0) bits |= kErrInfeasible;
   if (s0 >= s1) bits |= kErrSRange;
   if (sd_start[b] < 0) bits |= kErrSdStartNeg;
+  if (lower_ge_upper) bits |= kErrLowerGeUpper;
   if (N < 2) bits |= kErrTooFew;
   ws.err_bits[b] = bits;
   ws.s_start[b] = s0;
@@ -367,6 +393,73 @@ __global__ void k_setup_cartesian(int B, int N, const double *path_start, const 
   ws.sdd_start[b] = sdd_start ? sdd_start[b] : 0.0;
   ws.t_start[b] = t_start[b];
   ws.delta[b] = delta[b];
+}
+
+// K1 for Cartesian paths with the joint count fixed at compile time: the arithmetic of
+// k_cartesian_rows, but the rows stay on chip -- (q', q'') pairs and the two Cartesian B
+// values go to the sample's record ([q'_d, q''_d]*D | bt, br | m, type), the LP reads them
+// from LDS, FindSddMax/Min from registers. grid = (ceil(N/TPB), B); dynamic LDS:
+//   lim_lo[C] | lim_hi[C] | q'[D][TPB] | q''[D][TPB] | extras[2][TPB]
+template <int WORDS, int D>
+__global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Workspace ws) {
+  extern __shared__ double lds[];
+  constexpr int C = 2 * D + 2;
+  const int TPB = blockDim.x;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  double *s_lo = lds, *s_hi = s_lo + C;
+  double *s_Q1 = s_hi + C, *s_Q2 = s_Q1 + (size_t)D * TPB, *s_X = s_Q2 + (size_t)D * TPB;
+  for (int k = tid; k < 2 * C; k += TPB) s_lo[k] = ws.lim[(size_t)b * 2 * C + k];
+  __syncthreads();
+  const int i = blockIdx.x * TPB + tid;
+  if (i >= N) return;
+  const size_t o = (size_t)b * N + i;
+  const double inv = 1.0 / ws.delta[b];
+  const double *q = q_g + o * D;
+  const double *J = J_g + o * 6 * D;
+  double *rec = ws.q12 + o * (C + 2);
+  double *Q1 = s_Q1 + tid, *Q2 = s_Q2 + tid, *X = s_X + tid;
+  double q1r[D], q2r[D];
+  double v6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    double q1 = 0.0, q2 = 0.0;
+    if (i < N - 1) {
+      q1 = inv * (q[D + d] - q[d]);
+      if (i >= 1) {
+        const double q1n = (i + 1 < N - 1) ? inv * (q[2 * D + d] - q[D + d]) : 0.0;
+        q2 = inv * (q1n - q1);
+      }
+    }
+    q1r[d] = q1; q2r[d] = q2;
+    *reinterpret_cast<double2 *>(rec + 2 * d) = make_double2(q1, q2);
+    Q1[d * TPB] = q1;
+    Q2[d * TPB] = q2;
+#pragma unroll
+    for (int r = 0; r < 6; r++) v6[r] += J[r * D + d] * q1;
+  }
+  const double bt = (v6[0] * v6[0] + v6[1] * v6[1]) + v6[2] * v6[2];
+  const double br = (v6[3] * v6[3] + v6[4] * v6[4]) + v6[5] * v6[5];
+  *reinterpret_cast<double2 *>(rec + 2 * D) = make_double2(bt, br);
+  X[0] = bt;
+  X[TPB] = br;
+  LdsRowsJoint r;
+  r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
+  r.E = 2; r.X = X;
+  double sd2max, sddmax, sd2zero, x0 = 0.0, y0 = 0.0;
+  lp_find_max_sd2<WORDS>(r, C, &sd2max, &sddmax, &sd2zero);
+  {
+    // the two Cartesian rows have A = 0: like the velocity rows they only gate the result
+    const double vt = bt * sd2max, vr = br * sd2max;
+    const bool ok = !(vt + kTiny < s_lo[2 * D] || vt - kTiny > s_hi[2 * D]) &&
+                    !(vr + kTiny < s_lo[2 * D + 1] || vr - kTiny > s_hi[2 * D + 1]);
+    if (ok) find_sdd_both_joint_fixed<D>(q1r, q2r, s_hi, sd2max, &x0, &y0);
+  }
+  ws.m0[o] = sd2max;
+  ws.z0[o] = sd2zero;
+  ws.X0[o] = x0;
+  ws.Y0[o] = y0;
+  ws.at0[o] = fabs(sd2max - sd2zero) < kTiny;
 }
 
 // ------------------------------------------------ K1 (rows): validation + LP

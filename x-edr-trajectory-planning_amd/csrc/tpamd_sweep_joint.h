@@ -153,10 +153,14 @@ __device__ __forceinline__ double ext2(double a, double b) {
   return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b);
 }
 
-template <int D>
+// E: extra rows with A = 0 and an explicit B (Cartesian paths: 2, stored as one pair after
+// the D (q', q'') pairs); they behave like velocity rows with lower = -upper.
+template <int D, int E = 0>
 struct JointSweep {
   typedef JointLayout<D> L;
-  static constexpr int R = 2 * D + 2;                       // doubles per record
+  static_assert(E == 0 || E == 2, "extra rows come as one pair");
+  static constexpr int R = 2 * D + E + 2;                   // doubles per record
+  static constexpr int kMt = D + E / 2;                     // pair index of (sd2_max, type)
   static constexpr int kChunks = kTileSamples * R / 2;      // 16-byte chunks per tile
   static constexpr int kChunksPerLane = (kChunks + 63) / 64;
 #ifdef TPAMD_DIAG
@@ -177,6 +181,9 @@ struct JointSweep {
   double lim;             // the bound defining this lane's candidate
   double chk_hi[L::RPL];  // upper bounds of the acceleration rows this lane validates
   double vel_hi;          // upper bound of the velocity row this lane checks
+  double vel_lo;          // E > 0 only: its lower bound (0 for joint rows, -upper for extras)
+  int vel_mode;           // E > 0 only: B = x*x (0), x (1) or y (2) of the pair at vel_off
+  double ex_hi[E ? E : 1];   // E > 0 only: upper bounds of the extra rows (uniform)
   int own_off;            // offsets (in f64x2 units) of the pairs this lane reads
   int chk_off[L::RPL];
   int vel_off;
@@ -249,7 +256,7 @@ struct JointSweep {
     r.vel = p[vel_off];
   }
   __device__ __forceinline__ void load_mt(int idx, double &m, int &t) const {
-    const f64x2 v = record(idx)[D];
+    const f64x2 v = record(idx)[kMt];
     m = v.x;
     t = __double2loint(v.y);
   }
@@ -268,9 +275,18 @@ struct JointSweep {
   template <bool MAX>
   __device__ __forceinline__ double find_sdd(const Rows &r, double s2, int &win) const {
     constexpr double kSentinel = MAX ? -DBL_MAX : DBL_MAX;
-    // velocity row of this lane: v = q'^2 * sd2 against [0, (vmax*safety)^2]
-    const double vv = (r.vel.x * r.vel.x) * s2;
-    const bool vel_bad = (vv + kTiny < 0.0) | (vv - kTiny > vel_hi);
+    // velocity row of this lane: v = q'^2 * sd2 against [0, (vmax*safety)^2]; with extra
+    // rows some lanes check v = B * sd2 against [-upper, upper] instead
+    bool vel_bad;
+    if (E == 0) {
+      const double vv = (r.vel.x * r.vel.x) * s2;
+      vel_bad = (vv + kTiny < 0.0) | (vv - kTiny > vel_hi);
+    } else {
+      const double sel = (vel_mode == 2) ? r.vel.y : r.vel.x;
+      const double bb = (vel_mode == 0) ? sel * sel : sel;
+      const double vv = bb * s2;
+      vel_bad = (vv + kTiny < vel_lo) | (vv - kTiny > vel_hi);
+    }
     // candidate of this lane's group
     const double sddi = (lim - r.own.y * s2) / r.own.x;
     bool bad = (fabs(r.own.x) < kTiny) | (sddi != sddi);
@@ -321,6 +337,12 @@ struct JointSweep {
       const double vv = (pr.x * pr.x) * s2;
       bad = bad | (vv + kTiny < 0.0) | (vv - kTiny > vv_hi[i]);
     }
+    if (E > 0) {                              // extra rows (every lane: two cheap checks)
+      const f64x2 ex = p[D];
+      const double v0 = ex.x * s2, v1 = ex.y * s2;
+      bad = bad | (v0 + kTiny < -ex_hi[0]) | (v0 - kTiny > ex_hi[0]);
+      bad = bad | (v1 + kTiny < -ex_hi[E - 1]) | (v1 - kTiny > ex_hi[E - 1]);
+    }
 #pragma unroll
     for (int i = 0; i < L::CPL; i++) {       // this lane's other candidates
       const f64x2 own = p[v_off[i]];
@@ -337,11 +359,13 @@ struct JointSweep {
   // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
   __device__ __forceinline__ bool derivs_valid(int idx, double sddv, double s2) const {
     bool bad = false;
-    if (lane < 2 * D) {
-      const int d = (lane < D) ? lane : lane - D;
+    if (lane < 2 * D + E) {
+      const bool extra = lane >= 2 * D;
+      const int d = extra ? D : ((lane < D) ? lane : lane - D);      // pair index
       const f64x2 pr = *reinterpret_cast<const f64x2 *>(rec + (size_t)idx * R + 2 * d);
       const double A = (lane < D) ? pr.x : 0.0;
-      const double Bc = (lane < D) ? pr.y : pr.x * pr.x;
+      double Bc = (lane < D) ? pr.y : pr.x * pr.x;
+      if (E > 0 && extra) Bc = (lane == 2 * D) ? pr.x : pr.y;
       const double v = A * sddv + Bc * s2;
       bad = (v + kTiny < row_lo) || (v - kTiny > row_hi);
     }
@@ -574,7 +598,7 @@ struct JointSweep {
     if (k == K - 1) chain_next = cur;
     const bool exact = (__double_as_longlong(chain_next) == __double_as_longlong(my_new)) &&
                        chain_step_exact<FWD>(j, r, hi_r, arow, my_cur, my_sdd);
-    const f64x2 mt_j = record(j)[D], mt_n = record(jn)[D];
+    const f64x2 mt_j = record(j)[kMt], mt_n = record(jn)[kMt];
     const int t_j = __double2loint(mt_j.y), t_n = __double2loint(mt_n.y);
     const double m_j = mt_j.x, m_n = mt_n.x;
     const double nxt = sd2[jn];
@@ -767,9 +791,9 @@ struct JointSweep {
 
 // Dynamic LDS (bytes): sd2[N]*8 | tile rings WAVES*2*32*R*8 | type copy N (padded to 16) |
 // exchange words 16 B
-template <int D>
+template <int D, int E = 0>
 __host__ __device__ inline size_t sweep_joint_lds_bytes(int N, int waves) {
-  return (size_t)N * 8 + (size_t)waves * 2 * kTileSamples * (2 * D + 2) * 8 +
+  return (size_t)N * 8 + (size_t)waves * 2 * kTileSamples * (2 * D + E + 2) * 8 +
          (((size_t)N + 15) / 16) * 16 + 16;
 }
 
@@ -777,7 +801,7 @@ __host__ __device__ inline size_t sweep_joint_lds_bytes(int N, int waves) {
 // the tail, wave 1 the forward extremals; within one switching-point loop the two
 // extremals run concurrently (they are data-independent after the backward extremal's
 // first step, see add_extremal). Both waves keep identical copies of the loop scalars.
-template <int D, int WAVES>
+template <int D, int WAVES, int E = 0>
 __global__ void __launch_bounds__(64 * WAVES)
 k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
               double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
@@ -798,7 +822,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     }
     return;
   }
-  typedef JointSweep<D> JS;
+  typedef JointSweep<D, E> JS;
   JS S;
   S.N = N; S.lane = lane;
   S.ds = ws.ds[b];
@@ -812,7 +836,8 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   S.m_g = ws.m + pb;
   S.rec = src.q12 + pb * JS::R;
   S.tag0 = -1; S.tag1 = -1;
-  const double *lim_lo = src.lim + (size_t)b * 4 * D, *lim_hi = lim_lo + 2 * D;
+  constexpr int C = 2 * D + E;
+  const double *lim_lo = src.lim + (size_t)b * 2 * C, *lim_hi = lim_lo + C;
   {
     typedef JointLayout<D> L;
     const double kInf = __longlong_as_double(0x7ff0000000000000LL);
@@ -832,9 +857,21 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     const bool is_vel = lane < D;
     S.vel_off = is_vel ? lane : 0;
     S.vel_hi = is_vel ? lim_hi[D + lane] : kInf;
+    S.vel_lo = is_vel ? 0.0 : -kInf;
+    S.vel_mode = 0;
+    if (E > 0) {
+      if (lane >= D && lane < D + E) {          // lanes D, D+1: the extra rows
+        S.vel_off = D;
+        S.vel_mode = 1 + (lane - D);
+        S.vel_hi = lim_hi[2 * D + (lane - D)];
+        S.vel_lo = lim_lo[2 * D + (lane - D)];
+      }
+#pragma unroll
+      for (int k = 0; k < (E ? E : 1); k++) S.ex_hi[k] = lim_hi[2 * D + k];
+    }
   }
-  S.row_lo = (lane < 2 * D) ? lim_lo[lane] : 0.0;
-  S.row_hi = (lane < 2 * D) ? lim_hi[lane] : 0.0;
+  S.row_lo = (lane < C) ? lim_lo[lane] : 0.0;
+  S.row_hi = (lane < C) ? lim_hi[lane] : 0.0;
   {
     typedef JointLayout<D> L;
     const double kInf = __longlong_as_double(0x7ff0000000000000LL);
