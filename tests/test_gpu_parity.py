@@ -311,6 +311,59 @@ def test_engine_reproduces_committed_regression_vectors(env, golden_dir):
         np.testing.assert_array_equal(out["qdd"].cpu().numpy()[:, :, -1], stored[key + "/qdd_last_joint"])
 
 
+def test_api_limits_empty_batch_and_maximum_sizes(env):
+    syn, tpo, torch, eng, E = env["syn"], env["tpo"], env["torch"], env["eng"], env["E"]
+    # empty batch: a no-op that succeeds (reference: nothing to plan)
+    b = syn.make_joint_batch(1, 7, 100)
+    inp = eng.upload_joint_batch(b, env["dev"])
+    empty_in = {k: v[:0].contiguous() for k, v in inp.items()}
+    empty_out = eng.alloc_joint_outputs(0, 100, 7, env["dev"])
+    E.time_joint_paths(empty_in, empty_out, 100)
+    # sizes outside the supported range are refused with an error code, not clipped
+    out = eng.alloc_joint_outputs(1, 100, 7, env["dev"])
+    for bad_n in (2, 8193):
+        with pytest.raises(eng.TpamdError, match="unsupported"):
+            E.time_joint_paths(inp, out, bad_n)
+    b17 = syn.make_joint_batch(1, 17, 100)
+    with pytest.raises(eng.TpamdError, match="unsupported"):
+        E.time_joint_paths(eng.upload_joint_batch(b17, env["dev"]),
+                           eng.alloc_joint_outputs(1, 100, 17, env["dev"]), 100)
+    # the largest supported problem: D = 16, N = 8192 (generic kernels), and N = 8192 at D = 7
+    for D, N in ((16, 8192), (7, 8192)):
+        bb = syn.make_joint_batch(2, D, N)
+        ref = oracle_joint(env, bb, N)
+        _, o = solve_joint(env, bb, N, D)
+        np.testing.assert_array_equal(o["status"].cpu().numpy(), ref["status"])
+        ok = ref["status"] == 0
+        for k in ("time", "sd", "sdd", "qdd"):
+            np.testing.assert_array_equal(o[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
+
+
+def test_rows_mode_wide_constraint_sets(env):
+    """C = 33 and C = 64 rows per sample (two-word LP bit sets, candidate loop > 64 lanes)."""
+    tpo = env["tpo"]
+    rng = np.random.default_rng(3)
+    n = 120
+    for C in (33, 64):
+        s = np.linspace(0.0, 2.0, n)
+        a = rng.uniform(0.2, 1.5, (n, C)) * np.sign(rng.uniform(-1, 1, (1, C)))
+        a = a * (1.0 + 0.3 * np.sin(3.0 * s)[:, None])
+        bcoef = rng.uniform(-0.5, 0.5, (n, C)) * np.cos(2.0 * s)[:, None]
+        hi = rng.uniform(1.0, 3.0, (1, C)).repeat(n, 0)
+        lo = -rng.uniform(1.0, 3.0, (1, C)).repeat(n, 0)
+        a[:, C // 2:] = 0.0                               # velocity-like rows
+        bcoef[:, C // 2:] = np.abs(bcoef[:, C // 2:]) + 0.05
+        lo[:, C // 2:] = 0.0
+        p = tpo.Profile(n, C)
+        assert p.setup(a, bcoef, lo, hi, 0.0, 2.0, 0.0, 0.0, 0.0) == 0
+        rc = p.optimize()
+        out = _rows_solve(env, [(a, bcoef, lo, hi)], 0.0, 2.0, 0.0)
+        assert out["status"][0] == rc
+        if rc == 0:
+            for k in ("time", "sd", "sdd"):
+                np.testing.assert_array_equal(out[k][0], getattr(p, k), err_msg="C=%d %s" % (C, k))
+
+
 def test_joint_mode_bad_limits_fail_per_path(env):
     syn = env["syn"]
     b = syn.make_joint_batch(6, 7, 300)
