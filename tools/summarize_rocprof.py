@@ -16,6 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHORT = (("k_sweep", "k_sweep"), ("k_sample_lp_joint", "k_sample_lp"), ("k_lp_rows", "k_sample_lp"),
+         ("k_boundary_zfit", "k_boundary_zfit"), ("k_cartesian_lp", "k_sample_lp"),
          ("k_boundary_detect", "k_boundary_detect"), ("k_boundary_final", "k_boundary_final"),
          ("k_epilogue", "k_epilogue"), ("k_setup", "k_setup"))
 
