@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../oracle/tp_oracle.h"
+#include "../../x-edr-trajectory-planning_amd/host/batch_cartesian_timing.h"
 #include "../../x-edr-trajectory-planning_amd/host/batch_path_timing.h"
 #include "../../x-edr-trajectory-planning_amd/host/path_timing_trajectory.h"
 #include "../../x-edr-trajectory-planning_amd/host/time_optimal_path_timing.h"
@@ -302,11 +303,80 @@ static void TestMixedBatch() {
   }
 }
 
+// Cartesian batch: joint-spline samples stand in for the IK solution, the Jacobian callback
+// is a smooth function of q with a unit block (the reference's tests use test doubles for both,
+// path_timing_trajectory_test.cc:552-587). Every path must equal the oracle's Cartesian path.
+static void TestCartesianBatch() {
+  const int B = 10;
+  unsigned long long seed = 4242;
+  auto rnd = [&]() { seed = seed * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(seed >> 11) / 9007199254740992.0; };
+  std::vector<CartesianPathSamples> paths(B);
+  for (int b = 0; b < B; b++) {
+    const int D = (b % 2) ? 7 : 6, N = 200 + 50 * (b % 3), W = 5;
+    std::vector<VectorXd> wps;
+    for (int i = 0; i < W; i++) {
+      VectorXd v(D);
+      for (int d = 0; d < D; d++) v[d] = 4.0 * rnd() - 2.0;
+      wps.push_back(v);
+    }
+    double delta = 0;
+    auto jp = MakePath(N, wps, 1.0, 2.0, &delta);
+    CHECK(jp->SamplePath(0.0).ok());
+    CartesianPathSamples &p = paths[b];
+    for (int i = 0; i < N; i++) p.ik_positions.push_back(jp->GetPathPositionAt(i));
+    p.jacobian = [D](const VectorXd &q, double *J) {
+      for (int r = 0; r < 6; r++)
+        for (int d = 0; d < D; d++)
+          J[r * D + d] = 0.25 * std::sin(q[d] * (r + 1.0) + 0.37 * d) + ((r == d % 6) ? 1.0 : 0.0);
+      return ::tpamd::compat::OkStatus();
+    };
+    p.max_joint_velocity = VectorXd(D, 1.0 + rnd());
+    p.max_joint_acceleration = VectorXd(D, 2.0 + 2.0 * rnd());
+    p.max_translational_velocity = 0.6 + 0.9 * rnd();
+    p.max_rotational_velocity = 0.8 + 1.2 * rnd();
+    p.delta_parameter = delta;
+  }
+  const std::vector<CartesianPathSamples> copy = paths;
+  BatchCartesianTiming batch;
+  CHECK(batch.SetPaths(paths).ok());
+  BatchTimingResult r;
+  CHECK(batch.ComputeTimingProfiles(2.0, &r).ok());
+  for (int b = 0; b < B; b++) {
+    const CartesianPathSamples &p = copy[b];
+    const int N = (int)p.ik_positions.size(), D = (int)p.ik_positions[0].size();
+    std::vector<double> q(N * D), J(N * 6 * D), t(N), s(N), sd(N), sdd(N), qd(N * D), qdd(N * D);
+    for (int i = 0; i < N; i++) {
+      for (int d = 0; d < D; d++) q[i * D + d] = p.ik_positions[i][d];
+      CHECK(p.jacobian(p.ik_positions[i], &J[i * 6 * D]).ok());
+    }
+    int lei = 0;
+    const int rc = tpo_time_cartesian_path(q.data(), J.data(), N, D, p.max_joint_velocity.data(),
+                                           p.max_joint_acceleration.data(), p.max_translational_velocity,
+                                           p.max_rotational_velocity, 0.8, 0.0, p.delta_parameter, 0.0, 0.0, 2.0,
+                                           t.data(), s.data(), sd.data(), sdd.data(), qd.data(), qdd.data(), &lei);
+    CHECK(rc == r.status[b]);
+    if (rc != 0) continue;
+    CHECK(lei == r.last_extremal_index[b]);
+    const size_t so = r.sample_offset[b], jo = r.joint_offset[b];
+    for (int i = 0; i < N; i++) {
+      CHECK(r.time[so + i] == t[i]);
+      CHECK(r.sd[so + i] == sd[i]);
+      CHECK(r.sdd[so + i] == sdd[i]);
+    }
+    for (int i = 0; i < N * D; i++) {
+      CHECK(r.q[jo + i] == q[i]);
+      CHECK(r.qd[jo + i] == qd[i]);
+      CHECK(r.qdd[jo + i] == qdd[i]);
+    }
+  }
+}
+
 int main() {
   TestProfileAgainstOracle();
   TestJointPathAndPlanner();
   TestBatch();
   TestMixedBatch();
+  TestCartesianBatch();
   if (g_fail == 0) std::printf("ALL OK\n");
   else std::printf("%d CHECKS FAILED\n", g_fail);
   return g_fail == 0 ? 0 : 1;
