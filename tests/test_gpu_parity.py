@@ -364,6 +364,37 @@ def test_rows_mode_wide_constraint_sets(env):
                 np.testing.assert_array_equal(out[k][0], getattr(p, k), err_msg="C=%d %s" % (C, k))
 
 
+def test_device_entry_point_captures_into_a_hip_graph(env):
+    """the _device entries neither allocate (after reserve) nor synchronise,
+    so a whole batch solve can be captured once and replayed."""
+    syn, torch, eng, E = env["syn"], env["torch"], env["eng"], env["E"]
+    D, N, B = 7, 600, 16
+    b = syn.make_joint_batch(B, D, N)
+    ref = oracle_joint(env, b, N)
+    inp = eng.upload_joint_batch(b, env["dev"])
+    out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    E.reserve(B, N, 2 * D)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        E.time_joint_paths(inp, out, N, stream=side)          # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        E.time_joint_paths(inp, out, N, stream=side)
+    for k in ("time", "sd", "qdd"):
+        out[k].fill_(-1.0)
+    out["status"].fill_(-5)
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out["status"].cpu().numpy(), ref["status"])
+    ok = ref["status"] == 0
+    for k in ("time", "sd", "qdd"):
+        np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
+
+
 def test_joint_mode_bad_limits_fail_per_path(env):
     syn = env["syn"]
     b = syn.make_joint_batch(6, 7, 300)
