@@ -371,12 +371,101 @@ static void TestCartesianBatch() {
   }
 }
 
+// PlanBatch: several planners advance through their receding-horizon windows together
+// (one engine call per iteration and shape group); each must end exactly where its own
+// Plan() would have ended.
+static void TestPlanBatch() {
+  const int K = 6;
+  unsigned long long seed = 99;
+  auto rnd = [&]() { seed = seed * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(seed >> 11) / 9007199254740992.0; };
+  struct Spec { int D, N; std::vector<VectorXd> wps; double vmax, amax; };
+  std::vector<Spec> specs(K);
+  for (int k = 0; k < K; k++) {
+    Spec &sp = specs[k];
+    sp.D = (k == K - 1) ? 5 : 7;                 // the last planner is alone in its shape group
+    sp.N = (k == K - 1) ? 300 : 400;
+    const int W = 4 + (k % 2) * 3;               // long paths need several windows
+    for (int i = 0; i < W; i++) {
+      VectorXd v(sp.D);
+      for (int d = 0; d < sp.D; d++) v[d] = 6.0 * rnd() - 3.0;
+      sp.wps.push_back(v);
+    }
+    sp.vmax = 1.0 + rnd(); sp.amax = 2.0 + 2.0 * rnd();
+  }
+  auto make = [&](const Spec &sp, std::shared_ptr<TimeableJointSplinePath> *path_out) {
+    // a short sampling distance: one window covers only a part of the path
+    auto probe = std::make_shared<TimeableJointSplinePath>(
+        JointPathOptions().set_num_dofs(sp.D).set_num_path_samples(sp.N));
+    probe->SetWaypoints({sp.wps.data(), sp.wps.size()});
+    const double delta = 0.4 * probe->knots().back() / (sp.N - 1);
+    auto path = std::make_shared<TimeableJointSplinePath>(
+        JointPathOptions().set_num_dofs(sp.D).set_num_path_samples(sp.N).set_delta_parameter(delta));
+    std::vector<double> v(sp.D, sp.vmax), a(sp.D, sp.amax);
+    CHECK(path->SetMaxJointVelocity({v.data(), v.size()}).ok());
+    CHECK(path->SetMaxJointAcceleration({a.data(), a.size()}).ok());
+    CHECK(path->SetWaypoints({sp.wps.data(), sp.wps.size()}).ok());
+    *path_out = path;
+    auto planner = std::make_unique<PathTimingTrajectory>(
+        PathTimingTrajectoryOptions().SetNumDofs(sp.D).SetNumPathSamples(sp.N).SetTimeStep(Milliseconds(4)));
+    CHECK(planner->SetPath(path).ok());
+    return planner;
+  };
+  std::vector<std::shared_ptr<TimeableJointSplinePath>> paths_a(K), paths_b(K);
+  std::vector<std::unique_ptr<PathTimingTrajectory>> batch, single;
+  std::vector<PathTimingTrajectory *> ptrs;
+  for (int k = 0; k < K; k++) {
+    batch.push_back(make(specs[k], &paths_a[k]));
+    single.push_back(make(specs[k], &paths_b[k]));
+    ptrs.push_back(batch.back().get());
+  }
+  const auto st = PathTimingTrajectory::PlanBatch(ptrs, FromUnixSeconds(10.0), Seconds(1000.0));
+  for (int k = 0; k < K; k++) {
+    CHECK(st[k].ok());
+    CHECK(single[k]->Plan(FromUnixSeconds(10.0), Seconds(1000.0)).ok());
+    CHECK(batch[k]->IsTrajectoryAtEnd());
+    CHECK(batch[k]->GetTime() == single[k]->GetTime());
+    CHECK(batch[k]->GetTime().size() > 50);
+    CHECK(batch[k]->GetPositions().size() == single[k]->GetPositions().size());
+    for (size_t i = 0; i < std::min(batch[k]->GetPositions().size(), single[k]->GetPositions().size()); i++) {
+      CHECK(batch[k]->GetPositions()[i] == single[k]->GetPositions()[i]);
+      CHECK(batch[k]->GetVelocities()[i] == single[k]->GetVelocities()[i]);
+      CHECK(batch[k]->GetAccelerations()[i] == single[k]->GetAccelerations()[i]);
+    }
+    // the end of the path is reached with zero velocity
+    for (int d = 0; d < specs[k].D; d++) {
+      CHECK(std::fabs(batch[k]->GetPositions().back()[d] - specs[k].wps.back()[d]) < 1e-9);
+      CHECK(batch[k]->GetVelocities().back()[d] == 0.0);
+    }
+  }
+  // a short horizon: planners stop after the horizon is covered and can be continued
+  std::vector<std::unique_ptr<PathTimingTrajectory>> b2, s2;
+  std::vector<std::shared_ptr<TimeableJointSplinePath>> pa(K), pb(K);
+  std::vector<PathTimingTrajectory *> p2;
+  for (int k = 0; k < K; k++) { b2.push_back(make(specs[k], &pa[k])); s2.push_back(make(specs[k], &pb[k])); p2.push_back(b2.back().get()); }
+  const auto st2 = PathTimingTrajectory::PlanBatch(p2, FromUnixSeconds(0.0), Seconds(0.5));
+  for (int k = 0; k < K; k++) {
+    CHECK(st2[k].ok());
+    CHECK(s2[k]->Plan(FromUnixSeconds(0.0), Seconds(0.5)).ok());
+    CHECK(b2[k]->GetTime() == s2[k]->GetTime());
+    CHECK(b2[k]->IsTrajectoryAtEnd() == s2[k]->IsTrajectoryAtEnd());
+    CHECK(b2[k]->GetFinalDecelStart() == s2[k]->GetFinalDecelStart());
+  }
+  const auto st3 = PathTimingTrajectory::PlanBatch(p2, FromUnixSeconds(0.2), Seconds(1000.0));
+  for (int k = 0; k < K; k++) {
+    CHECK(st3[k].ok());
+    CHECK(s2[k]->Plan(FromUnixSeconds(0.2), Seconds(1000.0)).ok());
+    CHECK(b2[k]->GetTime() == s2[k]->GetTime());
+    CHECK(b2[k]->IsTrajectoryAtEnd());
+  }
+}
+
 int main() {
   TestProfileAgainstOracle();
   TestJointPathAndPlanner();
   TestBatch();
   TestMixedBatch();
   TestCartesianBatch();
+  TestPlanBatch();
   if (g_fail == 0) std::printf("ALL OK\n");
   else std::printf("%d CHECKS FAILED\n", g_fail);
   return g_fail == 0 ? 0 : 1;

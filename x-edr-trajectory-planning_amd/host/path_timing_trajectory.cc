@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <map>
+#include <tuple>
 
 #include "engine_handle.h"
 #include "timeable_path_joint_spline.h"
@@ -118,15 +120,15 @@ Status PathTimingTrajectory::HandleTimeArguments(Time start) {
   return OkStatus();
 }
 
-// One timing window (path_timing_trajectory.cc:307-475).
-Status PathTimingTrajectory::ComputeTimingProfile(Time start, Duration target_duration) {
+// One timing window (path_timing_trajectory.cc:307-475), phase 1: where the window starts.
+Status PathTimingTrajectory::BeginWindow(Time start, Duration target_duration, Window *w) {
   const double start_sec = TimeToSec(start);
   if (path_ == nullptr) return FailedPreconditionError("No path set");
   if (target_duration <= Seconds(0)) return InvalidArgumentError("Duration must be positive");
   const size_t N = options_.GetNumPathSamples(), D = options_.GetNumDofs();
-  const TimeablePath::State old_path_state = path_->GetState();
-  int path_samples_offset = 0;
-  if (old_path_state == TimeablePath::State::kNewPath) {
+  w->old_state = path_->GetState();
+  w->offset = 0;
+  if (w->old_state == TimeablePath::State::kNewPath) {
     path_start_ = 0.0;
     path_start_velocity_ = 0.0;
     path_start_acceleration_ = 0.0;
@@ -136,37 +138,25 @@ Status PathTimingTrajectory::ComputeTimingProfile(Time start, Duration target_du
     if (num == 0) return FailedPreconditionError("no previous window to connect to");
     const int lb = (int)(std::lower_bound(time_at_path_samples_.begin(), time_at_path_samples_.end(),
                                           start_sec) - time_at_path_samples_.begin());
-    path_samples_offset = std::clamp(lb - 1, 0, num - 1);
-    path_start_ = path_parameter_at_path_samples_[path_samples_offset];
-    path_start_velocity_ = path_velocity_at_path_samples_[path_samples_offset];
-    path_time_start_ = time_at_path_samples_[path_samples_offset];
+    w->offset = std::clamp(lb - 1, 0, num - 1);
+    path_start_ = path_parameter_at_path_samples_[w->offset];
+    path_start_velocity_ = path_velocity_at_path_samples_[w->offset];
+    path_time_start_ = time_at_path_samples_[w->offset];
   }
-  const double delta = path_->GetPathSamplingDistance();
-  path_horizon_ = path_start_ + delta * (path_->GetNumPathSamples() - 1);
+  w->delta = path_->GetPathSamplingDistance();
+  path_horizon_ = path_start_ + w->delta * (path_->GetNumPathSamples() - 1);
+  w->q.assign(N * D, 0.0); w->q1.assign(N * D, 0.0); w->q2.assign(N * D, 0.0);
+  w->qd.assign(N * D, 0.0); w->qdd.assign(N * D, 0.0);
+  w->t.assign(N, 0.0); w->s.assign(N, 0.0); w->sd.assign(N, 0.0); w->sdd.assign(N, 0.0); w->sd2.assign(N, 0.0);
+  w->status = -1;
+  return OkStatus();
+}
 
-  auto *joint = dynamic_cast<TimeableJointSplinePath *>(path_.get());
-  std::vector<double> q(N * D), q1(N * D), q2(N * D);
-  if (joint != nullptr) {
-    // sampling first: the start velocity is projected on q'(0) before the solve
-    tpamd_engine *engine = ::tpamd::shared_engine();
-    if (!engine) return InternalError("no GPU engine");
-    ::tpamd::EngineGuard guard;
-    const int rc = tpamd_sample_joint_paths_host(engine, 1, (int)D, (int)N, joint->num_control_points(),
-                                                 joint->knots().data(),
-                                                 joint->packed_control_points().data(), &path_start_,
-                                                 &delta, q.data(), q1.data(), q2.data());
-    if (rc != 0) return InternalError(tpamd_error_string(rc));
-    joint->AdoptSamples(path_start_, q.data(), q1.data(), q2.data());
-  } else {
-    Status st = path_->SamplePath(path_start_);
-    if (!st.ok()) return st;
-    st = path_->ConstraintSetup();
-    if (!st.ok()) return st;
-  }
-
-  if (old_path_state == TimeablePath::State::kModifiedPath ||
-      old_path_state == TimeablePath::State::kNewPath) {
-    // least-squares projection of the requested initial velocity on the start tangent
+// Phase 2 (after the path has been sampled): least-squares projection of the requested
+// initial velocity on the start tangent (path_timing_trajectory.cc:360-377).
+Status PathTimingTrajectory::ProjectStartVelocity(const Window &w) {
+  const size_t D = options_.GetNumDofs();
+  if (w.old_state == TimeablePath::State::kModifiedPath || w.old_state == TimeablePath::State::kNewPath) {
     const VectorXd &d0 = path_->GetFirstPathDerivativeAt(0);
     const double nrm2 = d0.squaredNorm();
     if (nrm2 > 100 * std::numeric_limits<double>::epsilon())
@@ -177,52 +167,127 @@ Status PathTimingTrajectory::ComputeTimingProfile(Time start, Duration target_du
     if (max_err > options_.GetMaxInitialVelocityError())
       return InvalidArgumentError("Could not satisfy initial velocity (probably not parallel to initial tangent)");
   }
+  return OkStatus();
+}
 
-  const int max_solver_loops = (int)std::max<size_t>(100, 10 * N);
-  std::vector<double> qd(N * D), qdd(N * D);
-  if (joint != nullptr) {
-    tpamd_engine *engine = ::tpamd::shared_engine();
+// Windows of TimeableJointSplinePath planners with equal shapes: ONE sampling call and ONE
+// solve for all of them (B = ids.size()).
+void PathTimingTrajectory::SolveJointWindows(const std::vector<PathTimingTrajectory *> &planners,
+                                             std::vector<Window> *windows, const std::vector<size_t> &ids,
+                                             std::vector<Status> *status) {
+  tpamd_engine *engine = ::tpamd::shared_engine();
+  if (!engine) {
+    for (size_t id : ids) (*status)[id] = InternalError("no GPU engine");
+    return;
+  }
+  const size_t B = ids.size();
+  auto *first = dynamic_cast<TimeableJointSplinePath *>(planners[ids[0]]->path_.get());
+  const size_t D = first->NumDofs(), N = first->NumPathSamples(), P = first->num_control_points();
+  std::vector<double> knots(B * (P + 3)), cps(B * P * D), vmax(B * D), amax(B * D), ps(B), dl(B), sd0(B),
+      sdd0(B), t0(B);
+  for (size_t g = 0; g < B; g++) {
+    PathTimingTrajectory *pl = planners[ids[g]];
+    auto *joint = dynamic_cast<TimeableJointSplinePath *>(pl->path_.get());
+    std::copy(joint->knots().begin(), joint->knots().end(), knots.begin() + g * (P + 3));
+    std::copy(joint->packed_control_points().begin(), joint->packed_control_points().end(),
+              cps.begin() + g * P * D);
+    for (size_t d = 0; d < D; d++) {
+      vmax[g * D + d] = joint->GetMaxJointVelocity()[d];
+      amax[g * D + d] = joint->GetMaxJointAcceleration()[d];
+    }
+    ps[g] = pl->path_start_; dl[g] = (*windows)[ids[g]].delta;
+  }
+  // sampling first: the start velocity is projected on q'(0) before the solve
+  std::vector<double> q(B * N * D), q1(B * N * D), q2(B * N * D);
+  {
     ::tpamd::EngineGuard guard;
-    tpamd_joint_batch batch{1, (int)D, (int)N, joint->num_control_points(), max_solver_loops, 0,
-                            joint->options().constraint_safety()};
-    tpamd_joint_inputs in{joint->knots().data(), joint->packed_control_points().data(),
-                          joint->GetMaxJointVelocity().data(), joint->GetMaxJointAcceleration().data(),
-                          &path_start_, &delta, &path_start_velocity_, &path_start_acceleration_,
-                          &path_time_start_, nullptr};
-    std::vector<double> t(N), s(N), sd(N), sdd(N), sd2(N);
-    int32_t lei = 0, status = -1;
-    double dtmax = 0;
-    tpamd_path_outputs out{t.data(), s.data(), sd.data(), sdd.data(), q.data(), qd.data(), qdd.data(),
-                           &lei, &dtmax, &status, sd2.data()};
-    const int rc = tpamd_time_joint_paths_host(engine, &batch, &in, &out);
-    if (rc != 0) return InternalError(tpamd_error_string(rc));
-    if (status >= 2 && status <= 6) return InternalError("Error setting up optimization problem");
-    if (status != 0) return InternalError("Error optimizing path parameter");
-    profile_.AdoptSolution((int)N, (int)(2 * D), path_start_, path_horizon_, t.data(), s.data(),
-                           sd.data(), sdd.data(), sd2.data(), lei, dtmax);
-  } else {
-    if (!profile_.InitSolver((int)N, (int)path_->NumConstraints()))
-      return InternalError("Error initializing solver.");
-    profile_.SetMaxNumSolverLoops(max_solver_loops);
-    if (!profile_.SetupProblem(path_->GetConstraints(), path_start_, path_horizon_, path_start_velocity_,
-                               path_start_acceleration_, path_time_start_))
-      return InternalError("Error setting up optimization problem");
-    if (!profile_.OptimizePathParameter()) return InternalError("Error optimizing path parameter");
-    // epilogue on the host for foreign path types (path_timing_trajectory.cc:458-472)
-    const VectorXd &amax = path_->GetMaxJointAcceleration();
-    for (size_t i = 0; i < N; i++) {
-      const double v = profile_.GetPathVelocity()[i], a = profile_.GetPathAcceleration()[i];
-      for (size_t d = 0; d < D; d++) {
-        q[i * D + d] = path_->GetPathPositionAt(i)[d];
-        const double d1 = path_->GetFirstPathDerivativeAt(i)[d], d2 = path_->GetSecondPathDerivativeAt(i)[d];
-        qd[i * D + d] = d1 * v;
-        qdd[i * D + d] = std::min(std::max(d1 * a + d2 * (v * v), -amax[d]), amax[d]);
-      }
+    const int rc = tpamd_sample_joint_paths_host(engine, (int)B, (int)D, (int)N, (int)P, knots.data(), cps.data(),
+                                                 ps.data(), dl.data(), q.data(), q1.data(), q2.data());
+    if (rc != 0) {
+      for (size_t id : ids) (*status)[id] = InternalError(tpamd_error_string(rc));
+      return;
     }
   }
+  std::vector<char> live(B, 1);
+  for (size_t g = 0; g < B; g++) {
+    PathTimingTrajectory *pl = planners[ids[g]];
+    auto *joint = dynamic_cast<TimeableJointSplinePath *>(pl->path_.get());
+    joint->AdoptSamples(pl->path_start_, &q[g * N * D], &q1[g * N * D], &q2[g * N * D]);
+    const Status st = pl->ProjectStartVelocity((*windows)[ids[g]]);
+    if (!st.ok()) { (*status)[ids[g]] = st; live[g] = 0; }
+    sd0[g] = pl->path_start_velocity_; sdd0[g] = pl->path_start_acceleration_; t0[g] = pl->path_time_start_;
+  }
+  std::vector<double> t(B * N), s(B * N), sd(B * N), sdd(B * N), sd2(B * N), qd(B * N * D), qdd(B * N * D),
+      dtmax(B);
+  std::vector<int32_t> lei(B, 0), st(B, -1);
+  const int max_solver_loops = (int)std::max<size_t>(100, 10 * N);
+  tpamd_joint_batch batch{(int)B, (int)D, (int)N, (int)P, max_solver_loops, 0, first->options().constraint_safety()};
+  tpamd_joint_inputs in{knots.data(), cps.data(), vmax.data(), amax.data(), ps.data(), dl.data(),
+                        sd0.data(), sdd0.data(), t0.data(), nullptr};
+  tpamd_path_outputs out{t.data(), s.data(), sd.data(), sdd.data(), q.data(), qd.data(), qdd.data(),
+                         lei.data(), dtmax.data(), st.data(), sd2.data()};
+  {
+    ::tpamd::EngineGuard guard;
+    const int rc = tpamd_time_joint_paths_host(engine, &batch, &in, &out);
+    if (rc != 0) {
+      for (size_t id : ids) (*status)[id] = InternalError(tpamd_error_string(rc));
+      return;
+    }
+  }
+  for (size_t g = 0; g < B; g++) {
+    if (!live[g]) continue;
+    Window &w = (*windows)[ids[g]];
+    w.status = st[g];
+    if (st[g] >= 2 && st[g] <= 6) { (*status)[ids[g]] = InternalError("Error setting up optimization problem"); continue; }
+    if (st[g] != 0) { (*status)[ids[g]] = InternalError("Error optimizing path parameter"); continue; }
+    auto cp = [&](std::vector<double> &dst, const std::vector<double> &src, size_t n) {
+      std::copy_n(src.begin() + g * n, n, dst.begin());
+    };
+    cp(w.t, t, N); cp(w.s, s, N); cp(w.sd, sd, N); cp(w.sdd, sdd, N); cp(w.sd2, sd2, N);
+    cp(w.q, q, N * D); cp(w.qd, qd, N * D); cp(w.qdd, qdd, N * D);
+    w.last_extremal_index = lei[g]; w.max_time_increment = dtmax[g];
+    PathTimingTrajectory *pl = planners[ids[g]];
+    pl->profile_.AdoptSolution((int)N, (int)(2 * D), pl->path_start_, pl->path_horizon_, w.t.data(), w.s.data(),
+                               w.sd.data(), w.sdd.data(), w.sd2.data(), w.last_extremal_index,
+                               w.max_time_increment);
+  }
+}
 
-  // Drop what the new window replaces, then append it (path_timing_trajectory.cc:418-456).
-  auto cut = [&](std::vector<double> &v, size_t stride) { v.resize((size_t)path_samples_offset * stride); };
+// Any other TimeablePath: its own SamplePath / ConstraintSetup, rows through the solver
+// mirror (which runs on the GPU), epilogue on the host (path_timing_trajectory.cc:458-472).
+Status PathTimingTrajectory::SolveWindowOnHost(Window *w) {
+  const size_t N = options_.GetNumPathSamples(), D = options_.GetNumDofs();
+  Status st = path_->SamplePath(path_start_);
+  if (!st.ok()) return st;
+  st = path_->ConstraintSetup();
+  if (!st.ok()) return st;
+  st = ProjectStartVelocity(*w);
+  if (!st.ok()) return st;
+  const int max_solver_loops = (int)std::max<size_t>(100, 10 * N);
+  if (!profile_.InitSolver((int)N, (int)path_->NumConstraints())) return InternalError("Error initializing solver.");
+  profile_.SetMaxNumSolverLoops(max_solver_loops);
+  if (!profile_.SetupProblem(path_->GetConstraints(), path_start_, path_horizon_, path_start_velocity_,
+                             path_start_acceleration_, path_time_start_))
+    return InternalError("Error setting up optimization problem");
+  if (!profile_.OptimizePathParameter()) return InternalError("Error optimizing path parameter");
+  const VectorXd &amax = path_->GetMaxJointAcceleration();
+  for (size_t i = 0; i < N; i++) {
+    const double v = profile_.GetPathVelocity()[i], a = profile_.GetPathAcceleration()[i];
+    for (size_t d = 0; d < D; d++) {
+      w->q[i * D + d] = path_->GetPathPositionAt(i)[d];
+      const double d1 = path_->GetFirstPathDerivativeAt(i)[d], d2 = path_->GetSecondPathDerivativeAt(i)[d];
+      w->qd[i * D + d] = d1 * v;
+      w->qdd[i * D + d] = std::min(std::max(d1 * a + d2 * (v * v), -amax[d]), amax[d]);
+    }
+  }
+  w->status = 0;
+  return OkStatus();
+}
+
+// Phase 3: drop what the new window replaces, then append it (path_timing_trajectory.cc:418-456).
+Status PathTimingTrajectory::EndWindow(Window *w) {
+  const size_t N = options_.GetNumPathSamples(), D = options_.GetNumDofs();
+  auto cut = [&](std::vector<double> &v, size_t stride) { v.resize((size_t)w->offset * stride); };
   cut(time_at_path_samples_, 1); cut(path_parameter_at_path_samples_, 1);
   cut(path_velocity_at_path_samples_, 1); cut(path_acceleration_at_path_samples_, 1);
   cut(position_at_path_samples_, D); cut(velocity_at_path_samples_, D); cut(acceleration_at_path_samples_, D);
@@ -231,14 +296,15 @@ Status PathTimingTrajectory::ComputeTimingProfile(Time start, Duration target_du
   app(path_parameter_at_path_samples_, profile_.GetPathParameter().data(), N);
   app(path_velocity_at_path_samples_, profile_.GetPathVelocity().data(), N);
   app(path_acceleration_at_path_samples_, profile_.GetPathAcceleration().data(), N);
-  app(position_at_path_samples_, q.data(), N * D);
-  app(velocity_at_path_samples_, qd.data(), N * D);
-  app(acceleration_at_path_samples_, qdd.data(), N * D);
+  app(position_at_path_samples_, w->q.data(), N * D);
+  app(velocity_at_path_samples_, w->qd.data(), N * D);
+  app(acceleration_at_path_samples_, w->qdd.data(), N * D);
   return OkStatus();
 }
 
-// path_timing_trajectory.cc:579-684
-Status PathTimingTrajectory::Plan(Time start, Duration time_horizon) {
+// path_timing_trajectory.cc:579-630: everything before the window loop.
+Status PathTimingTrajectory::PlanPrologue(Time start, Duration time_horizon, bool *needs_windows) {
+  *needs_windows = false;
   const double start_sec = TimeToSec(start);
   if (path_ == nullptr) return FailedPreconditionError("No path set.");
   if (Status st = HandleTimeArguments(start); !st.ok()) return st;
@@ -266,21 +332,13 @@ Status PathTimingTrajectory::Plan(Time start, Duration time_horizon) {
     keep(time_); keep(path_parameter_); keep(path_parameter_derivative_);
     keep(second_path_parameter_derivative_); keep(positions_); keep(velocities_); keep(accelerations_);
   }
-  Time loop_start_time = start;
-  bool time_horizon_reached = false;
-  const int N = (int)options_.GetNumPathSamples();
-  for (int loop = 0; !planned_to_end_ && !time_horizon_reached; loop++) {
-    if (Status st = ComputeTimingProfile(loop_start_time, start + time_horizon - loop_start_time); !st.ok())
-      return st;
-    const int decel_start = std::max(profile_.GetLastExtremalIndex(), N / 2);
-    final_decel_start_ = TimeFromSec(profile_.GetTimeSamples()[decel_start]);
-    planned_to_end_ = path_->CloseToEnd(path_horizon_);
-    time_horizon_reached = (profile_.GetTimeSamples()[N - 1] - TimeToSec(start)) > time_horizon / Seconds(1);
-    if (loop >= options_.GetMaxPlanningIterations())
-      return DeadlineExceededError("Reached maximum number of planning loops");
-    loop_start_time = final_decel_start_;
-  }
-  if (Status st = ResampleTrajectory(start_sec); !st.ok()) return st;
+  *needs_windows = true;
+  return OkStatus();
+}
+
+// path_timing_trajectory.cc:662-684: resample and bookkeeping after the window loop.
+Status PathTimingTrajectory::PlanEpilogue(Time start) {
+  if (Status st = ResampleTrajectory(TimeToSec(start)); !st.ok()) return st;
   initial_plan_ = true;
   if (!time_.empty()) {
     end_time_ = TimeFromSec(time_.back());
@@ -293,6 +351,73 @@ Status PathTimingTrajectory::Plan(Time start, Duration time_horizon) {
   }
   target_reached_ = planned_to_end_;
   return OkStatus();
+}
+
+// path_timing_trajectory.cc:579-684
+Status PathTimingTrajectory::Plan(Time start, Duration time_horizon) {
+  return PlanBatch({this}, start, time_horizon)[0];
+}
+
+std::vector<Status> PathTimingTrajectory::PlanBatch(const std::vector<PathTimingTrajectory *> &planners,
+                                                    Time start, Duration time_horizon) {
+  const size_t P = planners.size();
+  std::vector<Status> status(P, OkStatus());
+  std::vector<char> looping(P, 0), finish(P, 0);
+  std::vector<Time> loop_start(P, start);
+  std::vector<int> loop(P, 0);
+  std::vector<Window> windows(P);
+  for (size_t i = 0; i < P; i++) {
+    if (planners[i] == nullptr) { status[i] = InvalidArgumentError("null planner"); continue; }
+    bool needs = false;
+    status[i] = planners[i]->PlanPrologue(start, time_horizon, &needs);
+    // the loop condition of path_timing_trajectory.cc:632 is tested before the first window
+    if (status[i].ok() && needs) { looping[i] = !planners[i]->planned_to_end_; finish[i] = 1; }
+  }
+  for (;;) {
+    // phase 1 on the host, then group the joint-spline windows by shape
+    std::map<std::tuple<size_t, size_t, size_t, double>, std::vector<size_t>> groups;
+    std::vector<size_t> foreign;
+    bool any = false;
+    for (size_t i = 0; i < P; i++) {
+      if (!looping[i]) continue;
+      any = true;
+      PathTimingTrajectory *pl = planners[i];
+      status[i] = pl->BeginWindow(loop_start[i], start + time_horizon - loop_start[i], &windows[i]);
+      if (!status[i].ok()) { looping[i] = 0; finish[i] = 0; continue; }
+      if (auto *joint = dynamic_cast<TimeableJointSplinePath *>(pl->path_.get()))
+        groups[std::make_tuple(joint->NumDofs(), joint->NumPathSamples(), (size_t)joint->num_control_points(),
+                               joint->options().constraint_safety())].push_back(i);
+      else
+        foreign.push_back(i);
+    }
+    if (!any) break;
+    for (const auto &kv : groups) SolveJointWindows(planners, &windows, kv.second, &status);
+    for (size_t i : foreign) status[i] = planners[i]->SolveWindowOnHost(&windows[i]);
+    // phase 3 and the loop bookkeeping of path_timing_trajectory.cc:640-660
+    for (size_t i = 0; i < P; i++) {
+      if (!looping[i]) continue;
+      PathTimingTrajectory *pl = planners[i];
+      if (status[i].ok()) status[i] = pl->EndWindow(&windows[i]);
+      if (!status[i].ok()) { looping[i] = 0; finish[i] = 0; continue; }
+      const int N = (int)pl->options_.GetNumPathSamples();
+      const int decel_start = std::max(pl->profile_.GetLastExtremalIndex(), N / 2);
+      pl->final_decel_start_ = TimeFromSec(pl->profile_.GetTimeSamples()[decel_start]);
+      pl->planned_to_end_ = pl->path_->CloseToEnd(pl->path_horizon_);
+      const bool time_horizon_reached =
+          (pl->profile_.GetTimeSamples()[N - 1] - TimeToSec(start)) > time_horizon / Seconds(1);
+      if (loop[i] >= pl->options_.GetMaxPlanningIterations()) {
+        status[i] = DeadlineExceededError("Reached maximum number of planning loops");
+        looping[i] = 0; finish[i] = 0;
+        continue;
+      }
+      loop_start[i] = pl->final_decel_start_;
+      loop[i]++;
+      if (pl->planned_to_end_ || time_horizon_reached) looping[i] = 0;
+    }
+  }
+  for (size_t i = 0; i < P; i++)
+    if (finish[i] && status[i].ok()) status[i] = planners[i]->PlanEpilogue(start);
+  return status;
 }
 
 Status PathTimingTrajectory::ResampleTrajectory(double start_sec) {

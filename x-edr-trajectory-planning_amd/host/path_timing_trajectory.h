@@ -39,6 +39,13 @@ class PathTimingTrajectory : public TrajectoryPlanner {
  public:
   explicit PathTimingTrajectory(const PathTimingTrajectoryOptions &options);
   Status Plan(Time start, Duration time_horizon) override;
+  // Plan() for many planners at once: in every iteration of the
+  // receding-horizon loop (path_timing_trajectory.cc:632-660) the planning windows of all
+  // planners that still need one are sampled and solved by ONE engine call per group of
+  // equal (dofs, samples, control points, safety). Each planner ends in exactly the state
+  // Plan(start, time_horizon) would have left it in; the result holds one status per planner.
+  static std::vector<Status> PlanBatch(const std::vector<PathTimingTrajectory *> &planners, Time start,
+                                       Duration time_horizon);
   size_t NumTimeSamples() const { return time_.size(); }
   Time GetFinalDecelStart() const { return final_decel_start_; }
   Time GetNextPlanStartTime(Time target_time);
@@ -53,7 +60,26 @@ class PathTimingTrajectory : public TrajectoryPlanner {
  private:
   void UpdatePathTrackingStatus();
   Status HandleTimeArguments(Time start);
-  Status ComputeTimingProfile(Time start, Duration target_duration);
+  // One planning window (path_timing_trajectory.cc:307-475) in three phases, so that the
+  // engine calls between them can serve many planners at once.
+  struct Window {
+    int offset = 0;                          // path_samples_offset
+    TimeablePath::State old_state = TimeablePath::State::kNoPath;
+    double delta = 0.0;
+    std::vector<double> q, q1, q2, qd, qdd, t, s, sd, sdd, sd2;
+    int32_t last_extremal_index = 0, status = -1;
+    double max_time_increment = 0.0;
+  };
+  Status BeginWindow(Time start, Duration target_duration, Window *w);   // up to the path sampling
+  Status ProjectStartVelocity(const Window &w);                          // after sampling, :360-377
+  Status SolveWindowOnHost(Window *w);                                   // foreign TimeablePath types
+  Status EndWindow(Window *w);                                           // adopt + append, :418-456
+  // Plan() split around its window loop
+  Status PlanPrologue(Time start, Duration time_horizon, bool *needs_windows);
+  Status PlanEpilogue(Time start);
+  static void SolveJointWindows(const std::vector<PathTimingTrajectory *> &planners,
+                                std::vector<Window> *windows, const std::vector<size_t> &ids,
+                                std::vector<Status> *status);
   void ClampToTimeStepMultiple(Time *time);
   ::tpamd::compat::StatusOr<int> GetTimeOffsetAfter(Time time) const;
   Status ResampleTrajectory(double start_sec);
