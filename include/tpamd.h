@@ -249,6 +249,16 @@ int tpamd_resample_uniform_device(tpamd_engine *engine, const tpamd_resample_arg
 /* Same with HOST pointers in args (copies in, runs, copies out, synchronises). */
 int tpamd_resample_uniform_host(tpamd_engine *engine, const tpamd_resample_args *args);
 
+/* PathTimingTrajectory::ResampleSkippingSamplesCloserThanTimeStep
+ * (path_timing_trajectory.cc:785-836; TimeSamplingMethod::kSkipSamplesCloserThanTimeStep):
+ * the first output is interpolated at start_sec, then every path sample at least
+ * 0.95 * time_step (GetMinTimeDeltaToKeep, :893-900) after the last kept one is taken
+ * unchanged; the last output gets the end position and zero derivatives. Same argument
+ * struct; count[b] = number of outputs of path b (at most num_samples + 1). */
+int tpamd_resample_skip_device(tpamd_engine *engine, const tpamd_resample_args *args,
+                               void *hip_stream);
+int tpamd_resample_skip_host(tpamd_engine *engine, const tpamd_resample_args *args);
+
 /* ------------------------------------------------------------------------
  * Debug/inspection: copy the boundary curve of the LAST solve to host arrays
  * [B][N] (Boundary::sd2_max, sdd_max_for_sd2_max, sdd_min_for_sd2_max,

@@ -1153,6 +1153,60 @@ int tpo_resample_uniform(const double *time, const double *s, const double *sd,
   return M;
 }
 
+/* ResampleSkippingSamplesCloserThanTimeStep, path_timing_trajectory.cc:785-836: the
+ * first output is interpolated at start_sec (InterpolateAtTime :709-753), then every
+ * path sample at least min_delta (= 0.95 time_step, :893-900) after the last kept one is
+ * taken as it is; the last output gets the end position and zero derivatives. */
+int tpo_resample_skip(const double *time, const double *s, const double *sd,
+                      const double *sdd, const double *q, const double *qd,
+                      const double *qdd, int N, int D, double start_sec,
+                      double min_delta, const double *amax, int max_out,
+                      double *ot, double *os, double *osd, double *osdd,
+                      double *oq, double *oqd, double *oqdd) {
+  const int lower = lower_index_from(time, N, 0, start_sec);
+  const int upper = (N - 1 < lower + 1) ? N - 1 : lower + 1;
+  const double at = (fabs(time[upper] - time[lower]) < DBL_EPSILON)
+                        ? 0.5
+                        : (start_sec - time[lower]) / (time[upper] - time[lower]);
+  int M = 0;
+  double last = start_sec;
+  if (M < max_out) {
+    ot[0] = start_sec;
+    os[0] = lerp(at, s[lower], s[upper]);
+    osd[0] = lerp(at, sd[lower], sd[upper]);
+    osdd[0] = lerp(at, sdd[lower], sdd[upper]);
+    for (int d = 0; d < D; d++) {
+      const size_t kl = (size_t)lower * D + d, ku = (size_t)upper * D + d;
+      oq[d] = lerp(at, q[kl], q[ku]);
+      oqd[d] = lerp(at, qd[kl], qd[ku]);
+      double a = lerp(at, qdd[kl], qdd[ku]);
+      if (a < -amax[d]) a = -amax[d];
+      if (a > amax[d]) a = amax[d];
+      oqdd[d] = a;
+    }
+  }
+  M = 1;
+  for (int i = lower + 1; i < N; i++) {
+    if (fabs(time[i] - last) < min_delta) continue;
+    last = time[i];
+    if (M < max_out) {
+      ot[M] = time[i]; os[M] = s[i]; osd[M] = sd[i]; osdd[M] = sdd[i];
+      memcpy(oq + (size_t)M * D, q + (size_t)i * D, sizeof(double) * D);
+      memcpy(oqd + (size_t)M * D, qd + (size_t)i * D, sizeof(double) * D);
+      memcpy(oqdd + (size_t)M * D, qdd + (size_t)i * D, sizeof(double) * D);
+    }
+    M++;
+  }
+  if (M <= max_out) {
+    for (int d = 0; d < D; d++) {
+      oq[(size_t)(M - 1) * D + d] = q[(size_t)(N - 1) * D + d];
+      oqd[(size_t)(M - 1) * D + d] = 0.0;
+      oqdd[(size_t)(M - 1) * D + d] = 0.0;
+    }
+  }
+  return M;
+}
+
 /* ======================================================================= */
 /*                     whole hot path for one joint path                    */
 /* ======================================================================= */

@@ -184,6 +184,15 @@ int tpo_resample_uniform(const double *time, const double *s, const double *sd,
                          double time_step, const double *amax, int max_out,
                          double *ot, double *os, double *osd, double *osdd,
                          double *oq, double *oqd, double *oqdd);
+/* ResampleSkippingSamplesCloserThanTimeStep, path_timing_trajectory.cc:785-836;
+ * min_delta = GetMinTimeDeltaToKeep() = 0.95 * time step (path_timing_trajectory.cc:893-900).
+ * Returns the number of output samples; writes at most max_out. */
+int tpo_resample_skip(const double *time, const double *s, const double *sd,
+                      const double *sdd, const double *q, const double *qd,
+                      const double *qdd, int N, int D, double start_sec,
+                      double min_delta, const double *amax, int max_out,
+                      double *ot, double *os, double *osd, double *osdd,
+                      double *oq, double *oqd, double *oqdd);
 /* Number of uniform samples ResampleEquidistantlyInTime would produce (:756-757). */
 int tpo_resample_uniform_count(double end_time, double start_sec, double time_step);
 

@@ -103,6 +103,8 @@ def lib():
     L.tpo_epilogue.argtypes = [_dp, _dp, i, i, _dp, _dp, _dp, _dp, _dp]
     L.tpo_resample_uniform.restype = i
     L.tpo_resample_uniform.argtypes = [_dp] * 7 + [i, i, d, d, _dp, i] + [_dp] * 7
+    L.tpo_resample_skip.restype = i
+    L.tpo_resample_skip.argtypes = [_dp] * 7 + [i, i, d, d, _dp, i] + [_dp] * 7
     L.tpo_resample_uniform_count.restype = i
     L.tpo_resample_uniform_count.argtypes = [d, d, d]
     L.tpo_time_joint_path.restype = i
@@ -329,6 +331,19 @@ def resample_uniform(t, s, sd, sdd, q, qd, qdd, start_sec, time_step, amax):
                                N, D, float(start_sec), float(time_step), _f64(amax), M,
                                ot, os_, osd, osdd, oq, oqd, oqdd)
     return ot, os_, osd, osdd, oq, oqd, oqdd
+
+
+def resample_skip(t, s, sd, sdd, q, qd, qdd, start_sec, time_step, amax):
+    """kSkipSamplesCloserThanTimeStep resample; returns the kept samples only."""
+    q = _f64(q)
+    N, D = q.shape
+    cap = N + 1
+    ot, os_, osd, osdd = (np.zeros(cap) for _ in range(4))
+    oq, oqd, oqdd = (np.zeros((cap, D)) for _ in range(3))
+    M = lib().tpo_resample_skip(_f64(t), _f64(s), _f64(sd), _f64(sdd), q, _f64(qd), _f64(qdd),
+                                N, D, float(start_sec), 0.95 * float(time_step), _f64(amax), cap,
+                                ot, os_, osd, osdd, oq, oqd, oqdd)
+    return tuple(a[:M] for a in (ot, os_, osd, osdd, oq, oqd, oqdd))
 
 
 # ------------------------------------------------------------ whole hot path

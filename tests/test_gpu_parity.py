@@ -480,6 +480,32 @@ def test_query_and_resample_match_oracle(env):
         np.testing.assert_array_equal(ro["out_q"][i, M - 1].cpu().numpy(), out["q"][i, -1].cpu().numpy())
         assert float(ro["out_qd"][i, M - 1].abs().max()) == 0.0
 
+    # kSkipSamplesCloserThanTimeStep (path_timing_trajectory.cc:785-836), two time steps: one
+    # denser than the path samples (nothing skipped) and one much coarser, from a start time
+    # inside the trajectory
+    for dt_skip, start_at in ((1e-6, 0.0), (0.05, 0.37), (0.004, 0.0)):
+        start = np.full(B, start_at)
+        refs = [tpo.resample_skip(t[i], *[out[k][i].cpu().numpy() for k in
+                                          ("s", "sd", "sdd", "q", "qd", "qdd")],
+                                  start_at, dt_skip, b["amax"][i]) for i in range(B)]
+        cap = N + 1
+        ro = dict(out_time=torch.zeros(B, cap, **f), out_s=torch.zeros(B, cap, **f),
+                  out_sd=torch.zeros(B, cap, **f), out_sdd=torch.zeros(B, cap, **f),
+                  out_q=torch.zeros(B, cap, D, **f), out_qd=torch.zeros(B, cap, D, **f),
+                  out_qdd=torch.zeros(B, cap, D, **f),
+                  count=torch.zeros(B, dtype=torch.int32, device=env["dev"]))
+        E.resample_uniform(out, inp["max_acceleration"], torch.from_numpy(start).to(env["dev"]), dt_skip,
+                           ro, skip=True)
+        torch.cuda.synchronize()
+        cnt = ro["count"].cpu().numpy()
+        for i in range(B):
+            M = len(refs[i][0])
+            assert cnt[i] == M and M >= 2
+            for k, ref in zip(("out_time", "out_s", "out_sd", "out_sdd", "out_q", "out_qd", "out_qdd"), refs[i]):
+                np.testing.assert_array_equal(ro[k][i, :M].cpu().numpy(), ref, err_msg="%s dt=%g" % (k, dt_skip))
+            gaps = np.diff(ro["out_time"][i, :M].cpu().numpy())
+            assert (gaps >= 0.95 * dt_skip - 1e-15).all()
+
 
 # ---------------------------------------------- BASELINE-size batch: properties
 def test_config2_full_size_properties(env):

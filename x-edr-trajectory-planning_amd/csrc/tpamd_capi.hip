@@ -832,8 +832,10 @@ int tpamd_query_device(tpamd_engine *e, int B, int N, int K, const double *time,
   return 0;
 }
 
-int tpamd_resample_uniform_device(tpamd_engine *e, const tpamd_resample_args *a,
-                                  void *hip_stream) {
+}  // extern "C"
+
+namespace {
+int resample_device(tpamd_engine *e, const tpamd_resample_args *a, void *hip_stream, bool skip_mode) {
   if (!e || !a) return TPAMD_E_INVALID_ARGUMENT;
   if (a->num_paths <= 0) return a->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
   if (a->num_samples < 2 || a->num_dofs < 1 || a->max_out < 1 || !(a->time_step > 0))
@@ -850,13 +852,20 @@ int tpamd_resample_uniform_device(tpamd_engine *e, const tpamd_resample_args *a,
   p.start_sec = a->start_sec; p.time_step = a->time_step; p.status = a->status;
   p.ot = a->out_time; p.os = a->out_s; p.osd = a->out_sd; p.osdd = a->out_sdd;
   p.oq = a->out_q; p.oqd = a->out_qd; p.oqdd = a->out_qdd; p.count = a->count;
-  hipLaunchKernelGGL(k_resample, dim3((a->max_out + 255) / 256, a->num_paths), dim3(256), 0,
-                     (hipStream_t)hip_stream, p);
+  if (skip_mode) {
+    if (a->num_samples > 32768) return TPAMD_E_UNSUPPORTED;
+    p.time_step = 0.95 * a->time_step;   // GetMinTimeDeltaToKeep, path_timing_trajectory.cc:893-900
+    hipLaunchKernelGGL(k_resample_skip, dim3(a->num_paths), dim3(64), (size_t)a->num_samples * 4,
+                       (hipStream_t)hip_stream, p);
+  } else {
+    hipLaunchKernelGGL(k_resample, dim3((a->max_out + 255) / 256, a->num_paths), dim3(256), 0,
+                       (hipStream_t)hip_stream, p);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-int tpamd_resample_uniform_host(tpamd_engine *e, const tpamd_resample_args *a) {
+int resample_host(tpamd_engine *e, const tpamd_resample_args *a, bool skip_mode) {
   if (!e || !a) return TPAMD_E_INVALID_ARGUMENT;
   if (a->num_paths <= 0) return a->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
   const size_t B = a->num_paths, N = a->num_samples, D = a->num_dofs, M = a->max_out;
@@ -895,7 +904,7 @@ int tpamd_resample_uniform_host(tpamd_engine *e, const tpamd_resample_args *a) {
     da.max_acceleration = d_am; da.start_sec = d_st; da.status = d_status;
     da.out_time = o_t; da.out_s = o_s; da.out_sd = o_sd; da.out_sdd = o_sdd;
     da.out_q = o_q; da.out_qd = o_qd; da.out_qdd = o_qdd; da.count = o_cnt;
-    int rc = tpamd_resample_uniform_device(e, &da, st);
+    int rc = resample_device(e, &da, st, skip_mode);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(a->out_time, o_t, B * M * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(a->out_s, o_s, B * M * 8, hipMemcpyDeviceToHost, st));
@@ -908,6 +917,22 @@ int tpamd_resample_uniform_host(tpamd_engine *e, const tpamd_resample_args *a) {
     HIPCHK(hipStreamSynchronize(st));
   }
   return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int tpamd_resample_uniform_device(tpamd_engine *e, const tpamd_resample_args *a, void *hip_stream) {
+  return resample_device(e, a, hip_stream, false);
+}
+int tpamd_resample_uniform_host(tpamd_engine *e, const tpamd_resample_args *a) {
+  return resample_host(e, a, false);
+}
+int tpamd_resample_skip_device(tpamd_engine *e, const tpamd_resample_args *a, void *hip_stream) {
+  return resample_device(e, a, hip_stream, true);
+}
+int tpamd_resample_skip_host(tpamd_engine *e, const tpamd_resample_args *a) {
+  return resample_host(e, a, true);
 }
 
 int tpamd_debug_copy_boundary(tpamd_engine *e, int B, int N, double *sd2_max, double *sdd_max,

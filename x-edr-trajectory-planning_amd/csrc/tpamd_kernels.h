@@ -1326,4 +1326,84 @@ __global__ void k_resample(ResampleParams p) {
   }
 }
 
+// ResampleSkippingSamplesCloserThanTimeStep (path_timing_trajectory.cc:785-836), one
+// 64-lane wave per path. The "keep" decision is a sequential recurrence on the last kept
+// time (lane 0 walks the samples and records the kept indices in LDS); the first,
+// interpolated output and the copies of the kept samples are done by all lanes.
+// p.time_step carries the minimum time delta to keep (0.95 time step, :893-900).
+// Dynamic LDS: int[N].
+__global__ void __launch_bounds__(64) k_resample_skip(ResampleParams p) {
+  extern __shared__ int kept[];
+  __shared__ int s_count, s_lower;
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int N = p.N, D = p.D;
+  if (p.status && p.status[b] != 0) {
+    if (lane == 0) p.count[b] = 0;
+    return;
+  }
+  const double *tm = p.time + (size_t)b * N;
+  const double start = p.start_sec[b];
+  if (lane == 0) {
+    // TimeAtPathSamplesLowerIndex (:686-695): first i in [0, N-2] with tm[i+1] > start, else N-1
+    int lower = N - 1;
+    for (int i = 0; i < N - 1; i++)
+      if (tm[i + 1] > start) { lower = i; break; }
+    s_lower = lower;
+    int n = 0;
+    double last = start;
+    for (int i = lower + 1; i < N; i++) {
+      const double t = tm[i];
+      if (fabs(t - last) < p.time_step) continue;
+      last = t;
+      kept[n++] = i;
+    }
+    s_count = n + 1;
+    p.count[b] = n + 1;
+  }
+  __syncthreads();
+  const int M = s_count, lower = s_lower;
+  const int upper = (N - 1 < lower + 1) ? N - 1 : lower + 1;
+  const double at = (fabs(tm[upper] - tm[lower]) < DBL_EPSILON) ? 0.5 : (start - tm[lower]) / (tm[upper] - tm[lower]);
+  const size_t pb = (size_t)b * N;
+  for (int k = lane; k < M && k < p.max_out; k += 64) {
+    const size_t ob = (size_t)b * p.max_out + k;
+    const bool last_out = (k == M - 1);
+    if (k == 0) {
+      p.ot[ob] = start;
+      p.os[ob] = lerp_ref(at, p.s[pb + lower], p.s[pb + upper]);
+      p.osd[ob] = lerp_ref(at, p.sd[pb + lower], p.sd[pb + upper]);
+      p.osdd[ob] = lerp_ref(at, p.sdd[pb + lower], p.sdd[pb + upper]);
+    } else {
+      const int i = kept[k - 1];
+      p.ot[ob] = tm[i];
+      p.os[ob] = p.s[pb + i];
+      p.osd[ob] = p.sd[pb + i];
+      p.osdd[ob] = p.sdd[pb + i];
+    }
+    for (int d = 0; d < D; d++) {
+      double vq, vqd, vqdd;
+      if (last_out) {
+        vq = p.q[(pb + (N - 1)) * D + d];
+        vqd = 0.0; vqdd = 0.0;
+      } else if (k == 0) {
+        const double am = p.amax[(size_t)b * D + d];
+        vq = lerp_ref(at, p.q[(pb + lower) * D + d], p.q[(pb + upper) * D + d]);
+        vqd = lerp_ref(at, p.qd[(pb + lower) * D + d], p.qd[(pb + upper) * D + d]);
+        vqdd = lerp_ref(at, p.qdd[(pb + lower) * D + d], p.qdd[(pb + upper) * D + d]);
+        if (vqdd < -am) vqdd = -am;
+        if (vqdd > am) vqdd = am;
+      } else {
+        const int i = kept[k - 1];
+        vq = p.q[(pb + i) * D + d];
+        vqd = p.qd[(pb + i) * D + d];
+        vqdd = p.qdd[(pb + i) * D + d];
+      }
+      p.oq[ob * D + d] = vq;
+      p.oqd[ob * D + d] = vqd;
+      p.oqdd[ob * D + d] = vqdd;
+    }
+  }
+}
+
 }  // namespace tpamd

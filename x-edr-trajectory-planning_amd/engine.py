@@ -112,7 +112,7 @@ ABI_SYMBOLS = [
     "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
     "tpamd_time_cartesian_paths_device", "tpamd_time_cartesian_paths_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
-    "tpamd_resample_uniform_host",
+    "tpamd_resample_uniform_host", "tpamd_resample_skip_device", "tpamd_resample_skip_host",
     "tpamd_debug_copy_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
     "tpamd_profile_mean_ms", "tpamd_profile_kernel_name", "tpamd_profile_num_kernels",
 ]
@@ -169,6 +169,10 @@ def load_library():
     L.tpamd_resample_uniform_device.argtypes = [vp, C.POINTER(_ResampleArgs), vp]
     L.tpamd_resample_uniform_host.restype = i
     L.tpamd_resample_uniform_host.argtypes = [vp, C.POINTER(_ResampleArgs)]
+    L.tpamd_resample_skip_device.restype = i
+    L.tpamd_resample_skip_device.argtypes = [vp, C.POINTER(_ResampleArgs), vp]
+    L.tpamd_resample_skip_host.restype = i
+    L.tpamd_resample_skip_host.argtypes = [vp, C.POINTER(_ResampleArgs)]
     L.tpamd_debug_copy_boundary.restype = i
     L.tpamd_debug_copy_boundary.argtypes = [vp, i, i] + [vp] * 6
     L.tpamd_debug_copy_diag.restype = i
@@ -329,9 +333,11 @@ class Engine:
                                             _ptr(out_sd), _ptr(out_sdd), _ptr(ok),
                                             _stream_ptr(stream)), "tpamd_query_device")
 
-    def resample_uniform(self, sol, max_acceleration, start_sec, time_step, out, stream=None):
+    def resample_uniform(self, sol, max_acceleration, start_sec, time_step, out, stream=None,
+                         skip=False):
         """sol: dict time,s,sd,sdd [B][N], q,qd,qdd [B][N][D], status. out: dict out_time..
-        [B][max_out], out_q.. [B][max_out][D], count [B] int32."""
+        [B][max_out], out_q.. [B][max_out][D], count [B] int32. skip=True: the
+        kSkipSamplesCloserThanTimeStep method instead of the uniform one."""
         B, N, D = sol["q"].shape
         max_out = out["out_time"].shape[1]
         args = _ResampleArgs(
@@ -340,9 +346,9 @@ class Engine:
             _ptr(max_acceleration), _ptr(start_sec), float(time_step), _ptr(sol.get("status")),
             *[_ptr(out[k]) for k in ("out_time", "out_s", "out_sd", "out_sdd", "out_q",
                                      "out_qd", "out_qdd", "count")])
-        _check(self._lib.tpamd_resample_uniform_device(self._h, C.byref(args),
-                                                       _stream_ptr(stream)),
-               "tpamd_resample_uniform_device")
+        fn = self._lib.tpamd_resample_skip_device if skip else self._lib.tpamd_resample_uniform_device
+        _check(fn(self._h, C.byref(args), _stream_ptr(stream)),
+               "tpamd_resample_skip_device" if skip else "tpamd_resample_uniform_device")
 
     def debug_boundary(self, B, N):
         arr = {k: np.zeros((B, N)) for k in ("sd2_max", "sdd_max", "sdd_min", "sd2_zero", "sd2")}

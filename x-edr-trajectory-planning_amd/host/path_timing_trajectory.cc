@@ -472,50 +472,44 @@ Status PathTimingTrajectory::ResampleEquidistantlyInTime(double start_sec) {
   return OkStatus();
 }
 
-// path_timing_trajectory.cc:785-836 (host-side: SURVEY.md section 8f item 2).
+// path_timing_trajectory.cc:785-836 on the GPU (tpamd_resample_skip_host).
 void PathTimingTrajectory::ResampleSkippingSamplesCloserThanTimeStep(double start_sec) {
   const size_t D = options_.GetNumDofs();
   const int S = (int)time_at_path_samples_.size();
-  auto lower_index = [&](int from, double t) {
-    for (int i = from; i < S - 1; ++i) if (time_at_path_samples_[i + 1] > t) return i;
-    return S - 1;
-  };
   time_.clear(); positions_.clear(); velocities_.clear(); accelerations_.clear();
   path_parameter_.clear(); path_parameter_derivative_.clear(); second_path_parameter_derivative_.clear();
-  const int lo = lower_index(0, start_sec);
-  const int up = std::min(S - 1, lo + 1);
-  const double span = time_at_path_samples_[up] - time_at_path_samples_[lo];
-  const double at = std::fabs(span) < std::numeric_limits<double>::epsilon()
-                        ? 0.5 : (start_sec - time_at_path_samples_[lo]) / span;
-  auto lerp = [&](double a, double b) { return a + at * (b - a); };
-  auto row = [&](const std::vector<double> &v, int i) { return VectorXd(v.data() + (size_t)i * D, D); };
-  const VectorXd &amax = path_->GetMaxJointAcceleration();
-  VectorXd p0(D), v0(D), a0(D);
-  for (size_t d = 0; d < D; d++) {
-    p0[d] = lerp(position_at_path_samples_[(size_t)lo * D + d], position_at_path_samples_[(size_t)up * D + d]);
-    v0[d] = lerp(velocity_at_path_samples_[(size_t)lo * D + d], velocity_at_path_samples_[(size_t)up * D + d]);
-    a0[d] = std::min(std::max(lerp(acceleration_at_path_samples_[(size_t)lo * D + d],
-                                   acceleration_at_path_samples_[(size_t)up * D + d]), -amax[d]), amax[d]);
+  tpamd_engine *engine = ::tpamd::shared_engine();
+  if (!engine || S < 2) return;
+  const int cap = S + 1;
+  std::vector<double> ot(cap), os(cap), osd(cap), osdd(cap), oq((size_t)cap * D), oqd((size_t)cap * D),
+      oqdd((size_t)cap * D);
+  int32_t count = 0;
+  tpamd_resample_args a{};
+  a.num_paths = 1; a.num_samples = S; a.num_dofs = (int)D; a.max_out = cap;
+  a.time = time_at_path_samples_.data(); a.s = path_parameter_at_path_samples_.data();
+  a.sd = path_velocity_at_path_samples_.data(); a.sdd = path_acceleration_at_path_samples_.data();
+  a.q = position_at_path_samples_.data(); a.qd = velocity_at_path_samples_.data();
+  a.qdd = acceleration_at_path_samples_.data();
+  a.max_acceleration = path_->GetMaxJointAcceleration().data();
+  a.start_sec = &start_sec; a.time_step = time_step_sec_; a.status = nullptr;
+  a.out_time = ot.data(); a.out_s = os.data(); a.out_sd = osd.data(); a.out_sdd = osdd.data();
+  a.out_q = oq.data(); a.out_qd = oqd.data(); a.out_qdd = oqdd.data(); a.count = &count;
+  {
+    ::tpamd::EngineGuard guard;
+    if (tpamd_resample_skip_host(engine, &a) != 0) return;
   }
-  time_.push_back(start_sec); positions_.push_back(p0); velocities_.push_back(v0); accelerations_.push_back(a0);
-  path_parameter_.push_back(lerp(path_parameter_at_path_samples_[lo], path_parameter_at_path_samples_[up]));
-  path_parameter_derivative_.push_back(lerp(path_velocity_at_path_samples_[lo], path_velocity_at_path_samples_[up]));
-  second_path_parameter_derivative_.push_back(
-      lerp(path_acceleration_at_path_samples_[lo], path_acceleration_at_path_samples_[up]));
-  const double keep = GetMinTimeDeltaToKeep();
-  for (int i = lo + 1; i < S; ++i) {
-    if (std::fabs(time_at_path_samples_[i] - time_.back()) < keep) continue;
-    time_.push_back(time_at_path_samples_[i]);
-    positions_.push_back(row(position_at_path_samples_, i));
-    velocities_.push_back(row(velocity_at_path_samples_, i));
-    accelerations_.push_back(row(acceleration_at_path_samples_, i));
-    path_parameter_.push_back(path_parameter_at_path_samples_[i]);
-    path_parameter_derivative_.push_back(path_velocity_at_path_samples_[i]);
-    second_path_parameter_derivative_.push_back(path_acceleration_at_path_samples_[i]);
-  }
-  positions_.back() = row(position_at_path_samples_, S - 1);
-  velocities_.back().setZero();
-  accelerations_.back().setZero();
+  const int M = std::min<int>(count, cap);
+  time_.assign(ot.begin(), ot.begin() + M);
+  path_parameter_.assign(os.begin(), os.begin() + M);
+  path_parameter_derivative_.assign(osd.begin(), osd.begin() + M);
+  second_path_parameter_derivative_.assign(osdd.begin(), osdd.begin() + M);
+  positions_.assign(M, VectorXd(D)); velocities_.assign(M, VectorXd(D)); accelerations_.assign(M, VectorXd(D));
+  for (int i = 0; i < M; i++)
+    for (size_t d = 0; d < D; d++) {
+      positions_[i][d] = oq[(size_t)i * D + d];
+      velocities_[i][d] = oqd[(size_t)i * D + d];
+      accelerations_[i][d] = oqdd[(size_t)i * D + d];
+    }
 }
 
 }  // namespace trajectory_planning
