@@ -275,10 +275,11 @@ int tpamd_debug_copy_boundary(tpamd_engine *engine, int num_paths, int num_sampl
  * steps fwd/bwd). The product build leaves them zero. */
 int tpamd_debug_copy_diag(tpamd_engine *engine, int num_paths, long long *out);
 
-/* Name and average-launch bookkeeping of the dominant kernel for bench.py:
- * records HIP events around the sweep kernel of every solve on its own stream.
- * Returns the mean duration in milliseconds over the launches since the last
- * reset (0 if none). */
+/* Per-kernel launch durations for bench.py: HIP events recorded on the launch stream
+ * around each kernel (enable = 1) or around the sweep kernel only (enable = 2: two events
+ * per solve, so that the measurement barely disturbs the timed region); 0 switches it off.
+ * tpamd_profile_mean_ms returns the mean duration in milliseconds over the launches since
+ * the last reset (0 if none). */
 void tpamd_profile_reset(tpamd_engine *engine);
 void tpamd_profile_enable(tpamd_engine *engine, int enable);
 double tpamd_profile_mean_ms(tpamd_engine *engine, int kernel_index, int *num_launches);

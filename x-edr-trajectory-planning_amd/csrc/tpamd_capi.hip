@@ -64,7 +64,7 @@ struct tpamd_engine {
   size_t rows_bytes = 0;
   Workspace ws{};
   int last_B = 0, last_N = 0;
-  bool profile = false;
+  int profile = 0;             // 0 off, 1 every kernel, 2 the sweep kernel only
   bool force_generic = false;  // TPAMD_FORCE_GENERIC=1: A/B the specialised kernels
   std::vector<EventPair> events;
 };
@@ -151,7 +151,8 @@ struct Timer {
   int kernel;
   EventPair ev{};
   bool on;
-  Timer(tpamd_engine *e_, hipStream_t st_, int k) : e(e_), st(st_), kernel(k), on(e_->profile) {
+  Timer(tpamd_engine *e_, hipStream_t st_, int k)
+      : e(e_), st(st_), kernel(k), on(e_->profile == 1 || (e_->profile == 2 && k == KI_SWEEP)) {
     if (on) {
       (void)hipEventCreate(&ev.start);
       (void)hipEventCreate(&ev.stop);
@@ -962,7 +963,7 @@ int tpamd_debug_copy_diag(tpamd_engine *e, int B, long long *out) {
 }
 
 void tpamd_profile_enable(tpamd_engine *e, int enable) {
-  if (e) e->profile = enable != 0;
+  if (e) e->profile = (enable == 2) ? 2 : (enable != 0 ? 1 : 0);
 }
 
 void tpamd_profile_reset(tpamd_engine *e) {

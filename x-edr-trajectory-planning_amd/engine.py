@@ -366,7 +366,8 @@ class Engine:
 
     # ---------------------------------------------------------------- timing
     def profile_enable(self, on=True):
-        self._lib.tpamd_profile_enable(self._h, 1 if on else 0)
+        """True / 1: events around every kernel; 2: around the sweep kernel only; False: off."""
+        self._lib.tpamd_profile_enable(self._h, int(on) if on in (1, 2) else (1 if on else 0))
 
     def profile_reset(self):
         self._lib.tpamd_profile_reset(self._h)
