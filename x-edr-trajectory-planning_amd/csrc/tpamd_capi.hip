@@ -204,7 +204,7 @@ void configure_kernels_once() {
 // Returns true if the kernel also wrote qd/qdd (the planner epilogue).
 template <class Source>
 bool launch_sweep(hipStream_t st, int B, int N, int max_loops, const Source &src,
-                  const Workspace &ws, const tpamd_path_outputs *out, bool force_generic) {
+                  const Workspace &ws, const tpamd_path_outputs *out, bool /*force_generic*/) {
   const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
   hipLaunchKernelGGL((k_sweep<Source>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
                      out->time, out->s, out->sd, out->sdd, out->last_extremal_index,

@@ -618,10 +618,12 @@ __device__ __forceinline__ void wave_find_sdd_both(const R &r, int C, double sd2
     const double hi_i = __shfl(hi_m, i, 64), lo_i = __shfl(lo_m, i, 64);
     const double lim = (c & 1) ? hi_i : lo_i;
     const double sddi = (lim - bs) / A;
-    bool bad = (c >= 2 * C) | is_tiny(A) | (sddi != sddi);
+    bool bad = (c >= 2 * C) || is_tiny(A) || (sddi != sddi);
     for (int k = 0; k < C; k++) {
       const double v = wave_bcast_const(a_m, k) * sddi + wave_bcast_const(b_m, k) * sd2;
-      bad = bad | (v + kTiny < wave_bcast_const(lo_m, k)) | (v - kTiny > wave_bcast_const(hi_m, k));
+      const double lo_k = wave_bcast_const(lo_m, k), hi_k = wave_bcast_const(hi_m, k);
+      const bool under = v + kTiny < lo_k, over = v - kTiny > hi_k;
+      bad = bad || under || over;
     }
     if (!bad) {
       if (sddi > smax) smax = sddi;
@@ -958,10 +960,7 @@ __device__ __forceinline__ double wave_ordered_prefix(double d, double carry) {
 // check, sdd fill-in at extremal intersections, start acceleration, sqrt,
 // last_extremal_index_, time integration, outputs. `status` is the outcome of the
 // switching-point loop (0, 7 or 10). sd2 is an LDS array [N]; sdd is either an LDS
-// array (copy_sdd: written out at the end) or the output row itself. `pend`, when not
-// null, is an LDS bitmap of samples whose sdd entry still holds the numerator
-// 0.5*(sd2[i+-1] - sd2[i]) of a boundary-following step: the division by ds that the
-// reference performs at .cc:787/:877 is done here, off the sequential chain.
+// array (copy_sdd: written out at the end) or the output row itself.
 // The tail is run by ONE wave (the whole block in the generic kernel, wave 0 in the two-wave
 // kernel): stores of some lanes must be visible to loads of others, nothing more.
 __device__ __forceinline__ void tail_sync() {
@@ -972,7 +971,7 @@ __device__ __forceinline__ void tail_sync() {
 // Returns the path's final status.
 template <class Source>
 __device__ __forceinline__ int sweep_tail(const Source &src, const Workspace &ws, int b, int N, int stride,
-                           int lane, int status, double *sd2, double *sdd, const uint32_t *pend,
+                           int lane, int status, double *sd2, double *sdd,
                            bool copy_sdd, double *t_out, double *s_out, double *sd_out,
                            double *sdd_out, int32_t *lei_out, double *dtmax_out,
                            int32_t *status_out) {
@@ -980,11 +979,6 @@ __device__ __forceinline__ int sweep_tail(const Source &src, const Workspace &ws
   const double ds = ws.ds[b];
   const double *m = ws.m + pb;
   const int C = src.rows();
-  if (pend) {
-    for (int idx = lane; idx < N; idx += 64)
-      if (pend[idx >> 5] & (1u << (idx & 31))) sdd[idx] = sdd[idx] / ds;
-    tail_sync();
-  }
   // NaN check and sdd fill-in (.cc:398-411); every index is independent.
   if (status == 0) {
     bool has_nan = false;
@@ -1166,7 +1160,7 @@ k_sweep(int stride, int max_loops, Source src, Workspace ws, double *t_out, doub
     icrit_lo = iforw_hi;
   }
   __syncthreads();
-  sweep_tail(src, ws, b, N, stride, lane, status, lds, lds + N, nullptr, /*copy_sdd=*/true, t_out, s_out,
+  sweep_tail(src, ws, b, N, stride, lane, status, lds, lds + N, /*copy_sdd=*/true, t_out, s_out,
              sd_out, sdd_out, lei_out, dtmax_out, status_out);
 }
 

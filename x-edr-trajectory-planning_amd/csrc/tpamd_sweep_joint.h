@@ -325,7 +325,7 @@ struct JointSweep {
   // passes row r makes the answer "unknown" (false), never wrong: the step then falls to
   // the scalar code.
   template <bool MAX>
-  __device__ __forceinline__ bool chain_step_exact(int j, int r, double hi_r, f64x2 arow, double s2,
+  __device__ __forceinline__ bool chain_step_exact(int j, double hi_r, f64x2 arow, double s2,
                                                    double sddw) const {
     const f64x2 *p = record(j);
     bool bad = false;
@@ -597,7 +597,7 @@ struct JointSweep {
     double chain_next = __shfl_down(my_cur, G, 64);      // what the recurrence fed to step k+1
     if (k == K - 1) chain_next = cur;
     const bool exact = (__double_as_longlong(chain_next) == __double_as_longlong(my_new)) &&
-                       chain_step_exact<FWD>(j, r, hi_r, arow, my_cur, my_sdd);
+                       chain_step_exact<FWD>(j, hi_r, arow, my_cur, my_sdd);
     const f64x2 mt_j = record(j)[kMt], mt_n = record(jn)[kMt];
     const int t_j = __double2loint(mt_j.y), t_n = __double2loint(mt_n.y);
     const double m_j = mt_j.x, m_n = mt_n.x;
@@ -652,7 +652,6 @@ struct JointSweep {
   // partner's first step writes.
   __device__ __forceinline__ int add_extremal(int idx_start, Prefetch &pf, bool pair_signal = false,
                                               bool wait_pair = false) {
-    constexpr int dir = FWD ? 1 : -1;
 #define TPAMD_PAIR_SIGNAL()                                   \
   do {                                                        \
     if (pair_signal) {                                        \
@@ -1017,7 +1016,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   int fstatus = 0;
   if (w == 0) {
     TPAMD_T0(t0);
-    fstatus = sweep_tail(src, ws, b, N, stride, lane, status, sd2, S.sdd_g, nullptr, /*copy_sdd=*/false, t_out,
+    fstatus = sweep_tail(src, ws, b, N, stride, lane, status, sd2, S.sdd_g, /*copy_sdd=*/false, t_out,
                          s_out, sd_out, sdd_out, lei_out, dtmax_out, status_out);
     TPAMD_ACC(3, t0);
   }
