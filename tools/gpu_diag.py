@@ -17,7 +17,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 d = E.debug_diag(B).astype(np.float64)
 names = {0: "fwd extremals", 1: "bwd extremals", 2: "crit search", 3: "tail", 4: "chain cycles",
-         5: "whole loop", 6: "chain blocks", 7: "chain blocks, 0 verified", 8: "n boundary fwd", 9: "first pair cycles",
+         5: "whole loop", 6: "chain blocks", 7: "crit search mismatches (must be 0)", 8: "n boundary fwd", 9: "first pair cycles",
          10: "n findsdd fwd", 11: "loops", 12: "tile fills", 13: "tile fills w/o prefetch",
          14: "chain steps fwd", 15: "chain steps bwd"}
 for k, n in names.items():

@@ -692,7 +692,6 @@ struct JointSweep {
     do {                                                                                     \
       { TPAMD_T0(tc_); run = uniform_i32(follow_chain<FWD>(c, pf)); TPAMD_ACC(4, tc_); }     \
       TPAMD_CNT(6);                                                                          \
-      TPAMD_ADD(7, run == 0 ? 1 : 0);                                                        \
       total += run;                                                                          \
     } while (run == L::kChain && (FWD ? (c.idx < N - 2) : (c.idx > 1)));                     \
     trust = total > 0;                                                                       \
@@ -724,15 +723,21 @@ struct JointSweep {
 #undef TPAMD_PAIR_SIGNAL
   }
 
-  // NextCriticalPoint, .cc:697-720, as two wave-parallel scans over the LDS copies of
-  // type and sd2:
-  //  1. first idx in (lo, hi] classified source or trajectory -> c0 (none: -1);
-  //  2. first idx >= c0 whose sd2 is already set -> e (none: -1); the answer is the
-  //     last idx in (c0, e] with sd2_max[idx] == sd2_max_for_sdd0[0] (sic, index 0,
-  //     .cc:710; cached as bit kBndEqualsZ00 of the type byte), else c0.
-  // Each pass of the scan loops covers 256 samples (four 64-sample ballots whose LDS reads
-  // are issued together).
-  __device__ __forceinline__ int next_critical_point(int idx_lo, int idx_hi) const {
+  // NextCriticalPoint, .cc:697-720. The reference walks idx = lo+1 .. hi: the first sample
+  // classified source or trajectory becomes the candidate c0; after that every sample with
+  // sd2_max[idx] == sd2_max_for_sdd0[0] (sic, index 0, .cc:710; cached as bit kBndEqualsZ00
+  // of the type byte) replaces it; the walk returns at the first idx >= c0 whose sd2 is
+  // already set. Inside the switching-point loop that idx is always hi itself: sd2 is set
+  // on [0, icrit_lo] (forward extremals and the backward extremals that connected to them)
+  // and on [icrit_hi, N-1] (the first backward extremal), and nothing in between has been
+  // visited -- the forward extremal of a loop either stops below icrit_hi, leaving the next
+  // (icrit_lo, icrit_hi) untouched, or reaches the upper region, which ends the loop
+  // (.cc:337-341), and icrit_hi itself never moves after the first pair. So the answer is
+  // the last flagged idx in (c0, hi] if there is one, else c0, and since hi is fixed the
+  // last flagged idx <= hi (`zlast`) is found once per path (last_flagged_below).
+  // Each pass of the scan loop covers 256 samples (four 64-sample ballots whose LDS reads are
+  // issued together); successive searches scan disjoint ranges.
+  __device__ __forceinline__ int next_critical_point(int idx_lo, int idx_hi, int zlast) const {
     int c0 = -1;
     for (int base = idx_lo + 1; base <= idx_hi && c0 < 0; base += 256) {
       uint8_t ty[4];
@@ -749,43 +754,40 @@ struct JointSweep {
         if (mask[u]) c0 = base + 64 * u + __ffsll((long long)mask[u]) - 1;
     }
     if (c0 < 0) return -1;
-    int crit = c0;
-    for (int base = c0; base <= idx_hi; base += 256) {
+    return (zlast > c0) ? zlast : c0;
+  }
+
+  // Largest idx in [1, idx_hi] whose type byte carries kBndEqualsZ00, or -1.
+  __device__ __forceinline__ int last_flagged_below(int idx_hi) const {
+    for (int top = idx_hi; top >= 1; top -= 256) {
       uint8_t ty[4];
-      int hi32[4];
-      unsigned int lo32[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ty[u] = typel[max(top - 64 * u - lane, 0)];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int ic = min(base + 64 * u + lane, N - 1);
-        ty[u] = typel[ic];
-        const double v = sd2[ic];
-        hi32[u] = __double2hiint(v);
-        lo32[u] = (unsigned int)__double2loint(v);
-      }
-      unsigned long long mset[4], miso[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int idx = base + 64 * u + lane;
-        const bool in = idx <= idx_hi;
-        // !isnan(v): not (exponent all ones and mantissa non-zero)
-        const bool nan = ((hi32[u] & 0x7ff00000) == 0x7ff00000) & (((hi32[u] & 0x000fffff) | lo32[u]) != 0u);
-        mset[u] = __ballot(in & !nan);
-        miso[u] = __ballot(in & (idx > c0) & ((ty[u] & kBndEqualsZ00) != 0));
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (mset[u]) {
-          const int e = __ffsll((long long)mset[u]) - 1;
-          unsigned long long mi = miso[u];
-          if (e < 63) mi &= (2ull << e) - 1ull;
-          if (mi) crit = base + 64 * u + 63 - __clzll((long long)mi);
-          return crit;
-        }
-        if (miso[u]) crit = base + 64 * u + 63 - __clzll((long long)miso[u]);
+        const int idx = top - 64 * u - lane;
+        const unsigned long long m = __ballot((idx >= 1) & ((ty[u] & kBndEqualsZ00) != 0));
+        if (m) return top - 64 * u - (__ffsll((long long)m) - 1);
       }
     }
     return -1;
   }
+
+#ifdef TPAMD_DIAG
+  // The literal walk (first set sd2 found by scanning), to cross-check the shortcut above.
+  __device__ __forceinline__ int next_critical_point_literal(int idx_lo, int idx_hi) const {
+    int crit = -1;
+    for (int idx = idx_lo + 1; idx <= idx_hi; idx++) {
+      if (crit < 0) {
+        if (typel[idx] & (kBndSource | kBndTrajectory)) crit = idx;
+      } else if (typel[idx] & kBndEqualsZ00) {
+        crit = idx;
+      }
+      if (crit > 0 && !isnan(sd2[idx])) return crit;
+    }
+    return -1;
+  }
+#endif
 };
 
 // Dynamic LDS (bytes): sd2[N]*8 | tile rings WAVES*2*32*R*8 | type copy N (padded to 16) |
@@ -943,6 +945,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     iback_lo++;
   }
   icrit_lo = iforw_hi;
+  const int zlast = uniform_i32(S.last_flagged_below(icrit_hi));   // icrit_hi is final from here on
   const double *m_g = ws.m + pb;
   if (max_loops <= 0) max_loops = max(100, 10 * N);   // path_timing_trajectory.cc:398-400
   for (int loop = 0; loop < max_loops; loop++) {
@@ -951,8 +954,11 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     if (WAVES == 2) __syncthreads();   // sd2 writes of the other wave / the NaN mark are visible
     {
       TPAMD_T0(t0);
-      icrit = uniform_i32(S.next_critical_point(icrit_lo, icrit_hi));
+      icrit = uniform_i32(S.next_critical_point(icrit_lo, icrit_hi, zlast));
       TPAMD_ACC(2, t0);
+#ifdef TPAMD_DIAG
+      if (icrit != S.next_critical_point_literal(icrit_lo, icrit_hi)) TPAMD_CNT(7);
+#endif
     }
     if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
     if (icrit >= 1) {
