@@ -395,6 +395,24 @@ def test_device_entry_point_captures_into_a_hip_graph(env):
         np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
 
 
+def test_diagnostic_build_confirms_the_critical_point_shortcut(env):
+    """The sweep kernel replaces the sd2 scan of NextCriticalPoint by a loop invariant
+    (tpamd_sweep_joint.h); the diagnostic build also runs the literal walk and counts
+    disagreements."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    diag = env["eng"].DIAG_SO
+    if not os.path.exists(diag):
+        env["eng"].build_diagnostic_library()
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_crosscheck.py")],
+                         env=dict(os.environ, TPAMD_LIBRARY=diag), capture_output=True, text=True,
+                         timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    report = json.loads(res.stdout.strip().splitlines()[-1])
+    assert report["searches"] > 1000 and report["mismatches"] == 0, report
+
+
 def test_joint_mode_bad_limits_fail_per_path(env):
     syn = env["syn"]
     b = syn.make_joint_batch(6, 7, 300)

@@ -33,21 +33,34 @@ class TpamdError(RuntimeError):
     pass
 
 
+def _compile(target, extra_flags, force, verbose):
+    deps = [os.path.join(_CSRC, s) for s in _SOURCES] + [_HEADER]
+    stale = force or not os.path.exists(target) or any(
+        os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
+    if stale:
+        cmd = (["hipcc"] + HIPCC_FLAGS + list(extra_flags) +
+               ["-o", target, os.path.join(_CSRC, "tpamd_capi.hip")])
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=_CSRC)
+    return target
+
+
 def build_library(force=False, verbose=False, extra_flags=(), output=None):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
     global _SO
     if output is not None:
         _SO = output
-    deps = [os.path.join(_CSRC, s) for s in _SOURCES] + [_HEADER]
-    stale = force or not os.path.exists(_SO) or any(
-        os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps)
-    if stale:
-        cmd = (["hipcc"] + HIPCC_FLAGS + list(extra_flags) +
-               ["-o", _SO, os.path.join(_CSRC, "tpamd_capi.hip")])
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd, cwd=_CSRC)
-    return _SO
+    return _compile(_SO, extra_flags, force, verbose)
+
+
+DIAG_SO = os.path.join(_CSRC, "libtpamd_diag.so")
+
+
+def build_diagnostic_library(force=False, verbose=False):
+    """The -DTPAMD_DIAG variant: in-kernel cycle counters and the literal cross-checks of the
+    sweep kernel's shortcuts (tests/test_gpu_parity.py, tools/gpu_diag.py). Not the product."""
+    return _compile(DIAG_SO, ("-DTPAMD_DIAG",), force, verbose)
 
 
 class _JointBatch(C.Structure):
