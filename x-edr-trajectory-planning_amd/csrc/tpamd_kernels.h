@@ -987,27 +987,35 @@ __device__ __forceinline__ int sweep_tail(const Source &src, const Workspace &ws
     if (__any(has_nan)) status = 8;
   }
   if (status == 0) {
-    for (int idx = lane; idx < N; idx += 64) {
-      if (isnan(sdd[idx])) {
-        // ComputeSddAtIntersection (.cc:722-751) for this sample alone
-        const auto r = src.at(b, stride, idx);
-        const double s2 = sd2[idx];
-        const bool has_next = idx < N - 1, has_prev = idx > 0;
-        double res = 0.0;
-        bool done = false;
-        if (has_next && has_prev) {
-          const double c = 0.25 / ds * (sd2[idx + 1] - sd2[idx - 1]);
-          if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+    // four independent loads per lane in flight (sdd is a global array in the joint kernels)
+    for (int base = 0; base < N; base += 256) {
+      double cur[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) cur[u] = sdd[min(base + 64 * u + lane, N - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = base + 64 * u + lane;
+        if (idx < N && isnan(cur[u])) {
+          // ComputeSddAtIntersection (.cc:722-751) for this sample alone
+          const auto r = src.at(b, stride, idx);
+          const double s2 = sd2[idx];
+          const bool has_next = idx < N - 1, has_prev = idx > 0;
+          double res = 0.0;
+          bool done = false;
+          if (has_next && has_prev) {
+            const double c = 0.25 / ds * (sd2[idx + 1] - sd2[idx - 1]);
+            if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+          }
+          if (!done && has_next) {
+            const double c = 0.5 / ds * (sd2[idx + 1] - s2);
+            if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+          }
+          if (!done && has_prev) {
+            const double c = 0.5 / ds * (s2 - sd2[idx - 1]);
+            if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+          }
+          sdd[idx] = res;
         }
-        if (!done && has_next) {
-          const double c = 0.5 / ds * (sd2[idx + 1] - s2);
-          if (rows_valid(r, C, c, s2)) { res = c; done = true; }
-        }
-        if (!done && has_prev) {
-          const double c = 0.5 / ds * (s2 - sd2[idx - 1]);
-          if (rows_valid(r, C, c, s2)) { res = c; done = true; }
-        }
-        sdd[idx] = res;
       }
     }
     tail_sync();
@@ -1041,11 +1049,21 @@ __device__ __forceinline__ int sweep_tail(const Source &src, const Workspace &ws
   {
     const int start = (1 > N - 2) ? 1 : N - 2;
     bool found = false;
-    for (int top = start; top >= 1 && !found; top -= 64) {
-      const int idx = top - lane;
-      const bool hit = (idx >= 1) && (sdd[idx] > 0.0 || fabs(sd2[idx] - m[idx]) < kTiny);
-      const unsigned long long mask = __ballot(hit);
-      if (mask) { lei = top - (__ffsll((long long)mask) - 1); found = true; }
+    for (int top = start; top >= 1 && !found; top -= 256) {
+      double a[4], mm[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {          // unconditional, independent loads
+        const int ic = max(top - 64 * u - lane, 0);
+        a[u] = sdd[ic];
+        mm[u] = m[ic];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = top - 64 * u - lane;
+        const bool hit = (idx >= 1) & ((a[u] > 0.0) | (fabs(sd2[max(idx, 0)] - mm[u]) < kTiny));
+        const unsigned long long mask = __ballot(hit);
+        if (mask && !found) { lei = top - 64 * u - (__ffsll((long long)mask) - 1); found = true; }
+      }
     }
   }
 
