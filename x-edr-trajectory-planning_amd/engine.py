@@ -139,6 +139,13 @@ def load_library():
         raise TpamdError(
             "libtpamd.so is not built (%s). Run __graft_entry__.build(); there is no CPU "
             "fallback for the engine." % _SO)
+    # PyTorch ships its own HIP runtime; two runtimes in one process do not share devices.
+    # Import torch first so that libtpamd.so binds to the runtime torch uses, whatever the
+    # order the caller imports things in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_SO)
     vp, i = C.c_void_p, C.c_int
     L.tpamd_engine_create.restype = i
