@@ -525,6 +525,31 @@ def test_query_and_resample_match_oracle(env):
             assert (gaps >= 0.95 * dt_skip - 1e-15).all()
 
 
+@pytest.mark.parametrize("D,N,B,first", [(7, 2000, 3072, 5000), (6, 1500, 1024, 9000),
+                                         (14, 800, 512, 12000), (7, 333, 2048, 20000)])
+def test_wide_parity_sweep_against_the_oracle(env, D, N, B, first):
+    """Thousands of further paths (other seeds than the bench batch), with per-path limits,
+    start velocities and time offsets: every output of every path bit for bit."""
+    syn = env["syn"]
+    b = syn.make_joint_batch(B, D, N, first_path_index=first)
+    rng = np.random.default_rng(first)
+    b["vmax"] = b["vmax"] * rng.uniform(0.3, 3.0, (B, 1))
+    b["amax"] = b["amax"] * rng.uniform(0.2, 5.0, (B, 1))
+    b["sd_start"] = np.where(rng.uniform(size=B) < 0.3, rng.uniform(0.0, 0.2, B), 0.0)
+    b["time_start"] = rng.uniform(0.0, 100.0, B)
+    ref = oracle_joint(env, b, N)
+    _, out = solve_joint(env, b, N, D)
+    st = out["status"].cpu().numpy()
+    np.testing.assert_array_equal(st, ref["status"])
+    ok = st == 0
+    assert ok.mean() > 0.5
+    np.testing.assert_array_equal(out["last_extremal_index"].cpu().numpy()[ok],
+                                  ref["last_extremal_index"][ok])
+    for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+        np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok],
+                                      err_msg=k)
+
+
 # ---------------------------------------------- BASELINE-size batch: properties
 def test_config2_full_size_properties(env):
     """Config 2 of BASELINE.json (1024 paths, 7 dof, 2000 samples): size-independent
