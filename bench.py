@@ -6,7 +6,7 @@ boundary curve -> extremal sweeps -> time integration -> qd/qdd epilogue) over o
 batch of synthetic 7-DOF, 2000-sample joint-space paths already resident in HBM
 (BASELINE.json configs[1]: 1024 paths per GPU). With N > 1 every rank (one process
 per GPU) times its own shard of N*1024 paths and the packed timing profile
-(t, s, sd, sdd) is collected on rank 0 by ONE RCCL gather inside the timed region.
+(t, sd, sdd) is collected on rank 0 by ONE RCCL gather inside the timed region.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
@@ -122,16 +122,18 @@ def main():
     E = eng.Engine(dev_index)
     E.reserve(B, N, 2 * D)
     inp = eng.upload_joint_batch(batch, dev)
-    # timing profile packed as [4][B][N] so that the multi-GPU collection is ONE gather per
-    # batch; two output buffers, so that the gather of batch k (rank 0's inbound xGMI links)
+    # timing profile packed as [3][B][N] = (t, sd, sdd) so that the multi-GPU collection is ONE
+    # gather per batch (s is not sent: it is the arithmetic sequence s_start + i*ds of
+    # time_optimal_path_timing.cc:540-547, which the root rebuilds from per-path scalars);
+    # two output buffers, so that the gather of batch k (rank 0's inbound xGMI links)
     # overlaps the solve of batch k+1
-    G = shd.PipelinedGather((4, B, N), torch.float64, dev, depth=2)
+    G = shd.PipelinedGather((3, B, N), torch.float64, dev, depth=2)
     shared = eng.alloc_joint_outputs(B, N, D, dev)
     outs = []
     for slot in range(2):
         o = dict(shared)
         p = G.send[slot]
-        o["time"], o["s"], o["sd"], o["sdd"] = p[0], p[1], p[2], p[3]
+        o["time"], o["sd"], o["sdd"] = p[0], p[1], p[2]
         outs.append(o)
     counter = [0]
 
@@ -226,7 +228,7 @@ def main():
                        "paths_per_gpu": B, "total_paths": total_paths, "num_dofs": D,
                        "num_samples": N, "solved_paths": solved,
                        "gather": ("one RCCL gather of the packed timing profile "
-                                  "(t,s,sd,sdd: 4*N*8 B/path) to rank 0 per step, overlapped "
+                                  "(t,sd,sdd: 3*N*8 B/path; s = s_start + i*ds is rebuilt on the root) to rank 0 per step, overlapped "
                                   "with the next step's solve (double-buffered), all inside "
                                   "the timed region"
                                   if distributed else "none (single GPU)")},
