@@ -550,6 +550,32 @@ def test_wide_parity_sweep_against_the_oracle(env, D, N, B, first):
                                       err_msg=k)
 
 
+def test_pathological_inputs_terminate_and_match_the_oracle_status(env):
+    """NaN / inf / huge / denormal inputs in some paths of a batch: the call returns, the
+    other paths are unaffected, and every path reports the oracle's status."""
+    syn = env["syn"]
+    D, N, B = 7, 400, 16
+    b = syn.make_joint_batch(B, D, N)
+    b["control_points"][1, 5, 2] = np.nan
+    b["control_points"][2, :, :] = 0.0               # a path of zero length
+    b["vmax"][3, :] = np.inf
+    b["amax"][4, 0] = np.nan
+    b["control_points"][5] *= 1e150
+    b["control_points"][6] *= 1e-300
+    b["amax"][7, :] = 1e-310                         # denormal limits
+    b["delta"][8] = np.nan
+    b["vmax"][9, 3] = -1.0
+    b["knots"][10, 10] = np.nan
+    ref = oracle_joint(env, b, N)
+    _, out = solve_joint(env, b, N, D)
+    st = out["status"].cpu().numpy()
+    np.testing.assert_array_equal(st, ref["status"])
+    ok = st == 0
+    assert ok[0] and ok[11:].all()
+    for k in ("time", "sd", "qdd"):
+        np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
+
+
 # ---------------------------------------------- BASELINE-size batch: properties
 def test_config2_full_size_properties(env):
     """Config 2 of BASELINE.json (1024 paths, 7 dof, 2000 samples): size-independent
