@@ -164,8 +164,41 @@ def test_rows_mode_loop_limit_matches_oracle(env):
 
 
 # -------------------------------------------------------- joint mode vs oracle
+def test_generic_kernels_match_oracle_when_forced(env):
+    """TPAMD_FORCE_GENERIC=1 (read at engine creation) routes every joint count through the
+    generic kernels; they must give the same bits as the specialised ones."""
+    eng, syn, torch = env["eng"], env["syn"], env["torch"]
+    os.environ["TPAMD_FORCE_GENERIC"] = "1"
+    try:
+        E2 = eng.Engine(0)
+    finally:
+        del os.environ["TPAMD_FORCE_GENERIC"]
+    for D, N, B in ((7, 700, 12), (5, 400, 8), (6, 300, 6)):
+        b = syn.make_joint_batch(B, D, N)
+        ref = oracle_joint(env, b, N)
+        inp = eng.upload_joint_batch(b, env["dev"])
+        out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+        E2.time_joint_paths(inp, out, N)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(out["status"].cpu().numpy(), ref["status"])
+        ok = ref["status"] == 0
+        for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+            np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
+    cb = syn.make_cartesian_batch(6, 6, 300)
+    cref = env["tpo"].time_cartesian_batch(cb["ik_positions"], cb["jacobians"], cb["vmax"], cb["amax"],
+                                           cb["vtrans"], cb["vrot"], cb["path_start"], cb["delta"], nthreads=4)
+    cout = eng.alloc_joint_outputs(6, 300, 6, env["dev"])
+    E2.time_cartesian_paths(syn.upload_cartesian_batch(cb, env["dev"]), cout)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(cout["status"].cpu().numpy(), cref["status"])
+    okc = cref["status"] == 0
+    for k in ("time", "sd", "qdd"):
+        np.testing.assert_array_equal(cout[k].cpu().numpy()[okc], cref["t" if k == "time" else k][okc])
+
+
 @pytest.mark.parametrize("D,N,B", [(7, 500, 48), (7, 2000, 32), (6, 2000, 16), (14, 1000, 16),
-                                   (3, 1000, 8), (1, 64, 4), (16, 300, 4), (7, 3, 2), (7, 4096, 2)])
+                                   (3, 1000, 8), (4, 900, 8), (5, 1200, 8), (8, 700, 8),
+                                   (1, 64, 4), (16, 300, 4), (7, 3, 2), (7, 4096, 2)])
 def test_joint_mode_matches_oracle(env, D, N, B):
     b = env["syn"].make_joint_batch(B, D, N)
     ref = oracle_joint(env, b, N)

@@ -193,14 +193,22 @@ void configure_kernels_once() {
   allow_big_lds(k_sweep_joint<6, 2>);
   allow_big_lds(k_sweep_joint<7, 2>);
   allow_big_lds(k_sweep_joint<14, 2>);
+  allow_big_lds(k_sweep_joint<3, 2>);
+  allow_big_lds(k_sweep_joint<4, 2>);
+  allow_big_lds(k_sweep_joint<5, 2>);
+  allow_big_lds(k_sweep_joint<8, 2>);
+  allow_big_lds(k_sample_lp_joint<1, 3>);
+  allow_big_lds(k_sample_lp_joint<1, 4>);
+  allow_big_lds(k_sample_lp_joint<1, 5>);
+  allow_big_lds(k_sample_lp_joint<1, 8>);
   allow_big_lds(k_sweep_joint<6, 2, 2>);
   allow_big_lds(k_sweep_joint<7, 2, 2>);
   allow_big_lds(k_cartesian_lp<1, 6>);
   allow_big_lds(k_cartesian_lp<1, 7>);
 }
 
-// The sweep launch: joint-space batches with D in {6, 7, 14} (the BASELINE.json
-// configurations) take the specialised kernel, everything else the generic one.
+// The sweep launch: joint-space batches with D in {3..8, 14} take the specialised kernel
+// (6, 7, 14 are the BASELINE.json configurations), everything else the generic one.
 // Returns true if the kernel also wrote qd/qdd (the planner epilogue).
 template <class Source>
 bool launch_sweep(hipStream_t st, int B, int N, int max_loops, const Source &src,
@@ -240,6 +248,17 @@ bool launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, cons
   if (!force_generic && src.D == 6) { TPAMD_LAUNCH_JOINT(6); return true; }
   if (!force_generic && src.D == 14) { TPAMD_LAUNCH_JOINT(14); return true; }
 #undef TPAMD_LAUNCH_JOINT
+  // further joint counts: the two-wave kernel only
+#define TPAMD_LAUNCH_JOINT2(DD)                                                                  \
+  hipLaunchKernelGGL((k_sweep_joint<DD, 2>), dim3(B), dim3(128), sweep_joint_lds_bytes<DD>(N, 2), \
+                     st, N, max_loops, src, ws, out->time, out->s, out->sd, out->sdd,            \
+                     out->last_extremal_index, out->max_time_increment, out->status, out->qd,    \
+                     out->qdd)
+  if (!force_generic && src.D == 3) { TPAMD_LAUNCH_JOINT2(3); return true; }
+  if (!force_generic && src.D == 4) { TPAMD_LAUNCH_JOINT2(4); return true; }
+  if (!force_generic && src.D == 5) { TPAMD_LAUNCH_JOINT2(5); return true; }
+  if (!force_generic && src.D == 8) { TPAMD_LAUNCH_JOINT2(8); return true; }
+#undef TPAMD_LAUNCH_JOINT2
   hipLaunchKernelGGL((k_sweep<JointSource>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
                      out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
                      out->max_time_increment, out->status);
@@ -408,6 +427,10 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
     if (D == 7 && !e->force_generic) TPAMD_K1(7);
     else if (D == 6 && !e->force_generic) TPAMD_K1(6);
     else if (D == 14 && !e->force_generic) TPAMD_K1(14);
+    else if (D == 3 && !e->force_generic) TPAMD_K1(3);
+    else if (D == 4 && !e->force_generic) TPAMD_K1(4);
+    else if (D == 5 && !e->force_generic) TPAMD_K1(5);
+    else if (D == 8 && !e->force_generic) TPAMD_K1(8);
     else TPAMD_K1(0);
 #undef TPAMD_K1
   }

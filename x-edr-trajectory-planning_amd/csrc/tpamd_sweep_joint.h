@@ -851,7 +851,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 #pragma unroll
     for (int k = 0; k < L::RPL; k++) {
       int j = p + k * L::PARTS;
-      if (j >= D) j = p;                             // short share: re-check an own row
+      if (j >= D) j = (p < D) ? p : 0;               // short share: re-check a row again
       S.chk_off[k] = j;
       S.chk_hi[k] = lim_hi[j];
     }
