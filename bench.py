@@ -26,6 +26,15 @@ PKG = "x-edr-trajectory-planning_amd"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def baseline_metric():
+    """The metric string of BASELINE.json, verbatim."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "time-optimal path timings/s (7-DOF, 2000 s-samples), 1/2/4/8 MI355X + %HBM roofline"
+
+
 def algorithmic_bytes_per_path(D, N, P):
     """SURVEY.md 8(d) primary figure: inputs 8*(P*D + P+3 + 2D + 4) plus the outputs the
     north star names, t, s, sd, q: 8*N*(3+D)."""
@@ -217,7 +226,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(batch, N, D)
         line = {
-            "metric": "time-optimal path timings/s (7-DOF, 2000 s-samples)",
+            "metric": baseline_metric(),
             "value": round(value, 1), "unit": "paths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
