@@ -90,7 +90,10 @@ __device__ __forceinline__ long long tpamd_stamp() {
 #define TPAMD_ADD(slot, v)
 #endif
 
-constexpr int kTileSamples = 32;
+#ifndef TPAMD_TILE_SAMPLES
+#define TPAMD_TILE_SAMPLES 32
+#endif
+constexpr int kTileSamples = TPAMD_TILE_SAMPLES;
 
 // 16-byte pair as a native vector type: plain loads/stores that the compiler keeps in
 // registers (copies of HIP's f64x2 struct are emitted as memcpy and can pin the
