@@ -265,6 +265,18 @@ struct SlotSet {
       w[i] = (n >= lo + 64) ? ~0ull : (n > lo ? ((1ull << (n - lo)) - 1ull) : 0ull);
     }
   }
+  // drop the odd slots (lower bounds) of rows first_row .. : see lp_find_max_sd2
+  __device__ __forceinline__ void drop_lower_from(int first_row, int rows) {
+#pragma unroll
+    for (int i = 0; i < WORDS; i++) {
+      uint64_t m = 0;
+      for (int c = first_row; c < rows; c++) {
+        const int s = 2 * c + 1;
+        if ((s >> 6) == i) m |= 1ull << (s & 63);
+      }
+      w[i] &= ~m;
+    }
+  }
   __device__ __forceinline__ void set(int s) {
 #pragma unroll
     for (int i = 0; i < WORDS; i++)
@@ -332,10 +344,16 @@ __device__ __forceinline__ bool lp_pair_optimal(const R &r, int s1, int s2) {
 
 template <int WORDS, class R>
 __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddmax,
-                                double *sd2zero) {
+                                double *sd2zero, int b_only_from = -1) {
   typedef SlotSet<WORDS> Set;
   Set cset, act;
   cset.fill(2 * C);
+  // Rows b_only_from .. C-1 have A = 0, B >= 0 and lower <= 0 (the velocity rows of a joint
+  // path, the Cartesian rows). Their lower-bound slot can never be entered: on the line
+  // sdd = 0 (step 2) a row with B > 0 only offers its upper bound, and on a search line its
+  // crossing (lower - 0*a)/B is <= 0, never beyond the current sd2 > 0. Dropping those slots
+  // from the constraint set up front shortens every pass without changing any decision.
+  if (b_only_from >= 0) cset.drop_lower_from(b_only_from, C);
   act.clear();
 
   // Step 2: largest feasible sd2 on the line sdd = 0.
