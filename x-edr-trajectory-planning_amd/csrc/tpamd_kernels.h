@@ -54,6 +54,7 @@ struct JointSource {
   int D;
   int E = 0;          // extra B-only rows (Cartesian paths: 2)
   __device__ __forceinline__ int rows() const { return 2 * D + E; }
+  __device__ __forceinline__ int b_only_from() const { return D; }   // rows D.. have A = 0
   static constexpr bool kJoint = true;
   __device__ __forceinline__ int stride() const { return 2 * D + E + 2; }
   // final boundary value and classification into the sample's record
@@ -77,6 +78,7 @@ struct GenericSource {
   const double *A, *B, *LO, *HI;  // [B][N][C]
   int C;
   __device__ __forceinline__ int rows() const { return C; }
+  __device__ __forceinline__ int b_only_from() const { return -1; }
   static constexpr bool kJoint = false;
   __device__ __forceinline__ void put_record(int, int, int, double, uint8_t) const {}
   __device__ __forceinline__ GlobalRowsAt at(int b, int N, int idx) const {
@@ -600,26 +602,37 @@ __device__ __forceinline__ double final_m(const Workspace &ws, size_t pb, int N,
 // lane validates its candidate against all rows, wave reductions keep the extremes (the
 // value find_sdd_both returns: its visiting order and pruning do not change the result;
 // a NaN candidate is never selected there because it fails both comparisons).
+// b_only_from >= 0: rows b_only_from .. C-1 have A = 0 (velocity / Cartesian rows of a
+// joint-structured sample): they yield no candidates and their validity test does not
+// involve the candidate, so it is made once for the whole sample (as find_sdd_both_joint).
 template <class R>
 __device__ __forceinline__ void wave_find_sdd_both(const R &r, int C, double sd2, int lane,
-                                                   double *sdd_max, double *sdd_min) {
+                                                   double *sdd_max, double *sdd_min,
+                                                   int b_only_from = -1) {
   // lane k < C keeps row k in registers (one parallel load phase); the validity loop then
   // reads row k of every lane's candidate through readlane instead of re-loading it
   const bool has = lane < C;
   const double a_m = has ? r.a(lane) : 0.0, b_m = has ? r.b(lane) : 0.0;
   const double lo_m = has ? r.lo(lane) : 0.0, hi_m = has ? r.hi(lane) : 0.0;
+  const int Cc = (b_only_from >= 0) ? b_only_from : C;      // rows that depend on the candidate
+  bool fixed_bad = false;
+  if (b_only_from >= 0 && has && lane >= b_only_from) {
+    const double v = b_m * sd2;
+    fixed_bad = (v + kTiny < lo_m) || (v - kTiny > hi_m);
+  }
+  const bool none = __any(fixed_bad);
   double smax = -DBL_MAX, smin = DBL_MAX;
-  for (int c0 = 0; c0 < 2 * C; c0 += 64) {
+  for (int c0 = 0; c0 < 2 * Cc && !none; c0 += 64) {
     const int c = c0 + lane;
-    const int i = min(c >> 1, C - 1);
+    const int i = min(c >> 1, Cc - 1);
     const double A = __shfl(a_m, i, 64);
     const double bs = __shfl(b_m, i, 64) * sd2;
     // both shuffles outside any lane-dependent branch: a shuffle reads only active lanes
     const double hi_i = __shfl(hi_m, i, 64), lo_i = __shfl(lo_m, i, 64);
     const double lim = (c & 1) ? hi_i : lo_i;
     const double sddi = (lim - bs) / A;
-    bool bad = (c >= 2 * C) || is_tiny(A) || (sddi != sddi);
-    for (int k = 0; k < C; k++) {
+    bool bad = (c >= 2 * Cc) || is_tiny(A) || !(fabs(sddi) <= DBL_MAX);
+    for (int k = 0; k < Cc; k++) {
       const double v = wave_bcast_const(a_m, k) * sddi + wave_bcast_const(b_m, k) * sd2;
       const double lo_k = wave_bcast_const(lo_m, k), hi_k = wave_bcast_const(hi_m, k);
       const bool under = v + kTiny < lo_k, over = v - kTiny > hi_k;
@@ -662,7 +675,7 @@ __global__ void __launch_bounds__(256) k_boundary_zfit(int stride, Source src, W
     const int jj = blockIdx.x * 256 + s_list[it];
     const auto r = src.at(b, stride, jj);
     double x, y;
-    wave_find_sdd_both(r, src.rows(), ws.z0[pb + jj], lane, &x, &y);
+    wave_find_sdd_both(r, src.rows(), ws.z0[pb + jj], lane, &x, &y, src.b_only_from());
     if (lane == 0) { ws.Xz[pb + jj] = x; ws.Yz[pb + jj] = y; }
   }
 }
@@ -724,7 +737,7 @@ __global__ void __launch_bounds__(256) k_boundary_final(int stride, Source src, 
       const int jj = blockIdx.x * 256 + t;
       const auto r = src.at(b, stride, jj);
       double x, y;
-      wave_find_sdd_both(r, src.rows(), s_at[t], lane, &x, &y);
+      wave_find_sdd_both(r, src.rows(), s_at[t], lane, &x, &y, src.b_only_from());
       if (lane == 0) { s_X[t] = x; s_Y[t] = y; }
     }
   }
