@@ -651,6 +651,61 @@ __device__ __forceinline__ void wave_find_sdd_both(const R &r, int C, double sd2
   *sdd_min = smin;
 }
 
+// Same for small constraint sets, four samples per wave: each 16-lane group owns one sample
+// (rows in lanes 0..C-1 of the group, C <= 16, and its <= 16 candidates one per lane); rows are
+// broadcast inside the group with shuffles. `valid` is false for a group without a sample.
+template <class R>
+__device__ __forceinline__ void group16_find_sdd_both(const R &r, bool valid, int C, double sd2,
+                                                      int lane, double *sdd_max, double *sdd_min,
+                                                      int b_only_from) {
+  const int gl = lane & 15, gb = lane & 48;
+  const bool has = valid && gl < C;
+  const double a_m = has ? r.a(gl) : 0.0, b_m = has ? r.b(gl) : 0.0;
+  const double lo_m = has ? r.lo(gl) : 0.0, hi_m = has ? r.hi(gl) : 0.0;
+  const int Cc = (b_only_from >= 0) ? b_only_from : C;
+  bool fixed_bad = false;
+  if (b_only_from >= 0 && has && gl >= b_only_from) {
+    const double v = b_m * sd2;
+    fixed_bad = (v + kTiny < lo_m) || (v - kTiny > hi_m);
+  }
+  const unsigned long long fb = __ballot(fixed_bad);
+  const bool none = ((fb >> gb) & 0xFFFFull) != 0ull;
+  const int c = gl;
+  const int i = min(c >> 1, Cc - 1);
+  const double A = __shfl(a_m, gb + i, 64);
+  const double bs = __shfl(b_m, gb + i, 64) * sd2;
+  const double hi_i = __shfl(hi_m, gb + i, 64), lo_i = __shfl(lo_m, gb + i, 64);
+  const double lim = (c & 1) ? hi_i : lo_i;
+  const double sddi = (lim - bs) / A;
+  bool bad = none || !valid || (c >= 2 * Cc) || is_tiny(A) || !(fabs(sddi) <= DBL_MAX);
+  for (int k = 0; k < Cc; k++) {
+    const double a_k = __shfl(a_m, gb + k, 64), b_k = __shfl(b_m, gb + k, 64);
+    const double lo_k = __shfl(lo_m, gb + k, 64), hi_k = __shfl(hi_m, gb + k, 64);
+    const double v = a_k * sddi + b_k * sd2;
+    const bool under = v + kTiny < lo_k, over = v - kTiny > hi_k;
+    bad = bad || under || over;
+  }
+  double smax = bad ? -DBL_MAX : sddi, smin = bad ? DBL_MAX : sddi;
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    const double o1 = __shfl_xor(smax, off, 64), o2 = __shfl_xor(smin, off, 64);
+    smax = (o1 > smax) ? o1 : smax;
+    smin = (o2 < smin) ? o2 : smin;
+  }
+  if (smax == -DBL_MAX) smax = 0;
+  if (smin == DBL_MAX) smin = 0;
+  *sdd_max = smax;
+  *sdd_min = smin;
+}
+
+// Whether group16_find_sdd_both applies to a source.
+template <class Source>
+__device__ __forceinline__ bool fits_group16(const Source &src) {
+  const int C = src.rows();
+  const int Cc = (src.b_only_from() >= 0) ? src.b_only_from() : C;
+  return C <= 16 && 2 * Cc <= 16;
+}
+
 // CalculateBoundary pass 2, first half (.cc:1386-1395): the two neighbours of an isolated
 // point take sd2_max_for_sdd0 as their boundary value and FindSddMax/Min there. Those are
 // the only places (besides the deferred fixes, see k_boundary_final) where Xz/Yz are read,
@@ -671,6 +726,18 @@ __global__ void __launch_bounds__(256) k_boundary_zfit(int stride, Source src, W
   __syncthreads();
   const int count = s_count;
   const int lane = tid & 63;
+  if (fits_group16(src)) {
+    for (int it0 = (tid >> 6) * 4; it0 < count; it0 += 16) {     // four samples per wave
+      const int it = it0 + (lane >> 4);
+      const bool valid = it < count;
+      const int jj = blockIdx.x * 256 + s_list[valid ? it : 0];
+      const auto r = src.at(b, stride, jj);
+      double x, y;
+      group16_find_sdd_both(r, valid, src.rows(), ws.z0[pb + jj], lane, &x, &y, src.b_only_from());
+      if (valid && (lane & 15) == 0) { ws.Xz[pb + jj] = x; ws.Yz[pb + jj] = y; }
+    }
+    return;
+  }
   for (int it = tid >> 6; it < count; it += 4) {
     const int jj = blockIdx.x * 256 + s_list[it];
     const auto r = src.at(b, stride, jj);
@@ -732,13 +799,25 @@ __global__ void __launch_bounds__(256) k_boundary_final(int stride, Source src, 
   {
     const int count = s_count;
     const int lane = tid & 63;
-    for (int it = tid >> 6; it < count; it += 4) {
-      const int t = s_list[it];
-      const int jj = blockIdx.x * 256 + t;
-      const auto r = src.at(b, stride, jj);
-      double x, y;
-      wave_find_sdd_both(r, src.rows(), s_at[t], lane, &x, &y, src.b_only_from());
-      if (lane == 0) { s_X[t] = x; s_Y[t] = y; }
+    if (fits_group16(src)) {
+      for (int it0 = (tid >> 6) * 4; it0 < count; it0 += 16) {   // four samples per wave
+        const int it = it0 + (lane >> 4);
+        const bool valid = it < count;
+        const int t = s_list[valid ? it : 0];
+        const auto r = src.at(b, stride, blockIdx.x * 256 + t);
+        double x, y;
+        group16_find_sdd_both(r, valid, src.rows(), s_at[t], lane, &x, &y, src.b_only_from());
+        if (valid && (lane & 15) == 0) { s_X[t] = x; s_Y[t] = y; }
+      }
+    } else {
+      for (int it = tid >> 6; it < count; it += 4) {
+        const int t = s_list[it];
+        const int jj = blockIdx.x * 256 + t;
+        const auto r = src.at(b, stride, jj);
+        double x, y;
+        wave_find_sdd_both(r, src.rows(), s_at[t], lane, &x, &y, src.b_only_from());
+        if (lane == 0) { s_X[t] = x; s_Y[t] = y; }
+      }
     }
   }
   __syncthreads();
