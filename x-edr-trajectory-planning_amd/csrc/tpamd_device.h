@@ -282,6 +282,13 @@ struct SlotSet {
     for (int i = 0; i < WORDS; i++)
       if ((s >> 6) == i) w[i] |= 1ull << (s & 63);
   }
+  __device__ __forceinline__ bool has(int s) const {
+    bool h = false;
+#pragma unroll
+    for (int i = 0; i < WORDS; i++)
+      if ((s >> 6) == i) h = (w[i] >> (s & 63)) & 1ull;
+    return h;
+  }
   __device__ __forceinline__ bool any() const {
     uint64_t o = 0;
 #pragma unroll
@@ -342,9 +349,14 @@ __device__ __forceinline__ bool lp_pair_optimal(const R &r, int s1, int s2) {
   return t1 >= 0 && t2 >= 0;
 }
 
-template <int WORDS, class R>
+// SD > 0 (with SC = number of rows): the first SD rows' A and B are also available in the
+// register arrays ra / rb, and the two row scans below are unrolled over the SC rows with
+// static indices (no bit scans, no LDS reads for those rows) instead of walking the bit set;
+// slots are still visited in ascending order and with the same operations.
+template <int WORDS, class R, int SD = 0, int SC = 0>
 __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddmax,
-                                double *sd2zero, int b_only_from = -1) {
+                                double *sd2zero, int b_only_from = -1,
+                                const double *ra = nullptr, const double *rb = nullptr) {
   typedef SlotSet<WORDS> Set;
   Set cset, act;
   cset.fill(2 * C);
@@ -358,11 +370,10 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
 
   // Step 2: largest feasible sd2 on the line sdd = 0.
   double sd2 = DBL_MAX, sdd = 0.0;
-  for (int c = 0; c < C; c++) {
-    const double Bc = r.b(c);
-    if (fabs(Bc) < kTiny) continue;
+  auto step2_row = [&](int c, double Bc) {
+    if (fabs(Bc) < kTiny) return;
     if (Bc > kTiny) {
-      if (lp_cannot_pass(r.hi(c), Bc, 0.0, sd2 + kTiny)) continue;
+      if (lp_cannot_pass(r.hi(c), Bc, 0.0, sd2 + kTiny)) return;
       const double invB = 1.0 / Bc;
       const double tmp = r.hi(c) * invB;
       if (tmp < (sd2 + kTiny) && tmp > 0) {
@@ -371,7 +382,7 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
         sd2 = tmp;
       }
     } else if (Bc < -kTiny) {
-      if (lp_cannot_pass(r.lo(c), Bc, 0.0, sd2 + kTiny)) continue;
+      if (lp_cannot_pass(r.lo(c), Bc, 0.0, sd2 + kTiny)) return;
       const double invB = 1.0 / Bc;
       const double tmp = r.lo(c) * invB;
       if (tmp < (sd2 + kTiny) && tmp > 0) {
@@ -380,6 +391,12 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
         sd2 = tmp;
       }
     }
+  };
+  if (SD > 0) {
+#pragma unroll
+    for (int c = 0; c < SC; c++) step2_row(c, (c < SD) ? rb[c < SD ? c : 0] : r.b(c));
+  } else {
+    for (int c = 0; c < C; c++) step2_row(c, r.b(c));
   }
   if (sd2 > kMaxSd2 || !act.any()) {
     *sd2zero = kMaxSd2;
@@ -428,13 +445,10 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
 
     act.clear();
     double next_sd2 = DBL_MAX, next_sdd = 0.0;
-    for (int s = cset.next(0); s >= 0; s = cset.next(s + 1)) {
-      const int c = s >> 1;
-      const double Ac = r.a(c);
-      const double Bc = Ac * b + r.b(c);
-      if (fabs(Bc) < kTiny) continue;
-      const double lim = (s & 1) ? r.lo(c) : r.hi(c);
-      if (lp_cannot_pass(lim - Ac * a, Bc, sd2, next_sd2 + kTiny)) continue;
+    auto visit = [&](int s, double Ac, double Brow, double lim) {
+      const double Bc = Ac * b + Brow;
+      if (fabs(Bc) < kTiny) return;
+      if (lp_cannot_pass(lim - Ac * a, Bc, sd2, next_sd2 + kTiny)) return;
       const double invB = 1.0 / Bc;
       const double tmp = (lim - Ac * a) * invB;
       if (tmp < (next_sd2 + kTiny) && tmp > sd2) {
@@ -442,6 +456,20 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
         act.set(s);
         next_sd2 = tmp;
         next_sdd = a + b * next_sd2;
+      }
+    };
+    if (SD > 0) {
+#pragma unroll
+      for (int c = 0; c < SC; c++) {
+        const double Ac = (c < SD) ? ra[c < SD ? c : 0] : r.a(c);
+        const double Brow = (c < SD) ? rb[c < SD ? c : 0] : r.b(c);
+        if (cset.has(2 * c)) visit(2 * c, Ac, Brow, r.hi(c));
+        if (cset.has(2 * c + 1)) visit(2 * c + 1, Ac, Brow, r.lo(c));
+      }
+    } else {
+      for (int s = cset.next(0); s >= 0; s = cset.next(s + 1)) {
+        const int c = s >> 1;
+        visit(s, r.a(c), r.b(c), (s & 1) ? r.lo(c) : r.hi(c));
       }
     }
     if (!act.any()) {

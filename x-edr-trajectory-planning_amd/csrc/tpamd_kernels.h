@@ -247,7 +247,8 @@ __global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
   r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
   if (DT) {
     double sd2max, sddmax, sd2zero, x0, y0;
-    lp_find_max_sd2<WORDS>(r, C, &sd2max, &sddmax, &sd2zero, /*b_only_from=*/D);
+    lp_find_max_sd2<WORDS, LdsRowsJoint, DT, 2 * DT>(r, C, &sd2max, &sddmax, &sd2zero, /*b_only_from=*/D,
+                                                     q1r, q2r);
     find_sdd_both_joint_fixed<(DT ? DT : 1)>(q1r, q2r, s_hi, sd2max, &x0, &y0);
     ws.m0[o] = sd2max;
     ws.z0[o] = sd2zero;
@@ -449,7 +450,8 @@ __global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Work
   r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
   r.E = 2; r.X = X;
   double sd2max, sddmax, sd2zero, x0 = 0.0, y0 = 0.0;
-  lp_find_max_sd2<WORDS>(r, C, &sd2max, &sddmax, &sd2zero, /*b_only_from=*/D);
+  lp_find_max_sd2<WORDS, LdsRowsJoint, D, 2 * D + 2>(r, C, &sd2max, &sddmax, &sd2zero, /*b_only_from=*/D,
+                                                     q1r, q2r);
   {
     // the two Cartesian rows have A = 0: like the velocity rows they only gate the result
     const double vt = bt * sd2max, vr = br * sd2max;
