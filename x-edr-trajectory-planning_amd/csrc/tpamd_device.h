@@ -226,8 +226,12 @@ __device__ __forceinline__ void find_sdd_both_joint_fixed(const double (&a)[D], 
             bool bad = false;
 #pragma unroll
             for (int j = 0; j < D; j++) {
+              // (v + kTiny < -hi) || (v - kTiny > hi) in one comparison: for hi >= 0 only the
+              // term on v's own side can be true, and fl(v + kTiny) = -fl(-v - kTiny), so both
+              // cases read fl(|v| - kTiny) > hi. (hi < 0 makes lower >= upper: the path has
+              // failed its setup check and this value is never used.)
               const double v = a[j] * sddi + bs[j];
-              bad = bad | (v + kTiny < -hi[j]) | (v - kTiny > hi[j]);
+              bad = bad | (fabs(v) - kTiny > hi[j]);
             }
             if (!bad) {
               if (sddi > smax) smax = sddi;
