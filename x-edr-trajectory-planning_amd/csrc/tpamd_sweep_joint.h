@@ -513,12 +513,18 @@ struct JointSweep {
     const bool in_loop = FWD ? (j < N - 2) : (j > 1);
     bool elig = false;
     double m_jn = 0.0, m_j = 0.0;
-    if (in_loop && j >= 0 && j < N) {
-      const int jn = j + dir;
-      m_j = m_g[j];
-      m_jn = m_g[jn];
+    // The curve and the types come from the records in the two resident LDS tiles (no global
+    // latency); a step whose samples lie beyond them simply ends this call's run -- the caller
+    // re-centres the tiles and comes back.
+    const int jn = j + dir;
+    const int tj = max(j, 0) / kTileSamples, tjn = max(jn, 0) / kTileSamples;
+    const bool resident = (tj == tag0 || tj == tag1) && (tjn == tag0 || tjn == tag1);
+    if (in_loop && j >= 0 && j < N && resident) {
+      const f64x2 mt_j = record(j)[kMt], mt_n = record(jn)[kMt];
+      m_j = mt_j.x;
+      m_jn = mt_n.x;
       const double nxt = sd2[jn];
-      elig = (typel[j] & kBndTrajectory) && (typel[jn] & kBndTrajectory) &&
+      elig = (__double2loint(mt_j.y) & kBndTrajectory) && (__double2loint(mt_n.y) & kBndTrajectory) &&
              !(!isnan(nxt) && (nxt < m_jn)) && !(m_jn < 0);
     }
     const unsigned long long mask = __ballot(elig);
