@@ -359,13 +359,14 @@ struct JointSweep {
     return ((bm >> (lane & ~(L::GRP - 1))) & ((1ull << L::GRP) - 1ull)) == 0ull;
   }
 
-  // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j (rare path: global loads).
+  // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j. idx is always the extremal's
+  // current sample, whose record is in a resident tile.
   __device__ __forceinline__ bool derivs_valid(int idx, double sddv, double s2) const {
     bool bad = false;
     if (lane < 2 * D + E) {
       const bool extra = lane >= 2 * D;
       const int d = extra ? D : ((lane < D) ? lane : lane - D);      // pair index
-      const f64x2 pr = *reinterpret_cast<const f64x2 *>(rec + (size_t)idx * R + 2 * d);
+      const f64x2 pr = record(idx)[d];
       const double A = (lane < D) ? pr.x : 0.0;
       double Bc = (lane < D) ? pr.y : pr.x * pr.x;
       if (E > 0 && extra) Bc = (lane == 2 * D) ? pr.x : pr.y;
