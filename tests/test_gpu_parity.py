@@ -609,6 +609,39 @@ def test_pathological_inputs_terminate_and_match_the_oracle_status(env):
         np.testing.assert_array_equal(out[k].cpu().numpy()[ok], ref["t" if k == "time" else k][ok])
 
 
+def test_repeated_solves_are_bitwise_reproducible(env):
+    """The two waves of a path share sd2 in LDS and exchange results through barriers: a
+    race would show up as run-to-run differences. 300 solves of the bench batch and of a
+    Cartesian batch must reproduce the first one bit for bit."""
+    torch, syn, eng, E = env["torch"], env["syn"], env["eng"], env["E"]
+    D, N, B = 7, 2000, 1024
+    b = syn.make_joint_batch(B, D, N)
+    inp = eng.upload_joint_batch(b, env["dev"])
+    first = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    E.time_joint_paths(inp, first, N)
+    out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    keys = ("time", "s", "sd", "sdd", "qd", "qdd", "status", "last_extremal_index")
+    for it in range(300):
+        for k in ("time", "sd", "sdd", "qdd"):
+            out[k].fill_(float(it))
+        E.time_joint_paths(inp, out, N)
+        if it % 10 == 9 or it < 3:
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(out[k], first[k]), (k, it)
+    cb = syn.make_cartesian_batch(512, 6, 1500)
+    cin = syn.upload_cartesian_batch(cb, env["dev"])
+    cfirst = eng.alloc_joint_outputs(512, 1500, 6, env["dev"])
+    E.time_cartesian_paths(cin, cfirst)
+    cout = eng.alloc_joint_outputs(512, 1500, 6, env["dev"])
+    for it in range(100):
+        E.time_cartesian_paths(cin, cout)
+        if it % 10 == 9:
+            torch.cuda.synchronize()
+            for k in keys:
+                assert torch.equal(cout[k], cfirst[k]), (k, it)
+
+
 # ---------------------------------------------- BASELINE-size batch: properties
 def test_config2_full_size_properties(env):
     """Config 2 of BASELINE.json (1024 paths, 7 dof, 2000 samples): size-independent
