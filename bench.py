@@ -46,8 +46,12 @@ def cpu_baseline(batch, N, D):
     built in this image) timed on this box's host cores on the same inputs."""
     from oracle import tpo
     import numpy as np
-    cores = os.cpu_count() or 1
-    nthreads = max(1, min(cores, 64))
+    # one GPU's share of the host is 16 cores on the measurement boxes: stay within it
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    nthreads = max(1, min(cores, 16))
     B = batch["control_points"].shape[0]
 
     def run(n, nthreads):
