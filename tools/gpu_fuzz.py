@@ -53,7 +53,11 @@ def main():
     t_end = time.time() + budget
     cases = paths = 0
     failures = []
+    next_note = time.time() + 30.0
     while time.time() < t_end and len(failures) < 5:
+        if time.time() >= next_note:      # a progress line every half minute
+            print("[fuzz] %d cases, %d paths, %d failures" % (cases, paths, len(failures)), file=sys.stderr, flush=True)
+            next_note += 30.0
         kind = rng.choice(["joint", "joint", "ragged", "cartesian"])
         D = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 7, 7, 8, 9, 12, 14, 16]))
         N = int(rng.choice([3, 4, 17, 63, 64, 65, 128, 500, 1000, 2000, 2999]))
