@@ -2,15 +2,21 @@
 """Benchmark of the batched time-optimal path-timing hot path on MI355X.
 
 One "step" = one pass of the hot path (B-spline sampling -> constraint rows -> LP
-boundary curve -> extremal sweeps -> time integration -> qd/qdd epilogue) over one
-batch of synthetic 7-DOF, 2000-sample joint-space paths already resident in HBM
-(BASELINE.json configs[1]: 1024 paths per GPU). With N > 1 every rank (one process
-per GPU) times its own shard of N*1024 paths and the packed timing profile
-(t, sd, sdd) is collected on rank 0 by ONE RCCL gather inside the timed region.
+boundary curve -> extremal sweeps -> time integration -> qd/qdd) over one batch of
+synthetic 7-DOF, 2000-sample joint-space paths already resident in HBM.
+
+  python bench.py                         BASELINE.json configs[1]: 1024 paths on one GPU
+  ... --gpus N (under torch.distributed.run)   the same 1024 paths PER GPU ("weak" scaling), one
+                                          contiguous shard of the N*1024-path batch per rank, ONE
+                                          RCCL gather of the timing profile to rank 0 per step
+  ... --workload configs2                 BASELINE.json configs[2]: 8192 paths per GPU
+                                          (65536 over 8 GPUs)
+  ... --gather full                       gather q(t) as well (t, sd, sdd, q), in chunks
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -24,6 +30,11 @@ if ROOT not in sys.path:
 PKG = "x-edr-trajectory-planning_amd"
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+# fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-operations/s
+# (78.6 TFLOP/s when every operation is an FMA), i.e. one wave64 VALU instruction per SIMD
+# every 4 cycles.
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
+WORKLOADS = {"configs1": 1024, "configs2": 8192}
 
 
 def baseline_metric():
@@ -41,18 +52,55 @@ def algorithmic_bytes_per_path(D, N, P):
     return 8 * (P * D + P + 3 + 2 * D + 4) + 8 * N * (3 + D)
 
 
+def gather_bytes_per_path(mode, D, N):
+    """Bytes one path contributes to the gather payload: the packed timing profile
+    (t, sd, sdd; s = s_start + i*ds is rebuilt on the root) and, for "full", q as well."""
+    if mode == "none":
+        return 0
+    return 8 * N * 3 + (8 * N * D if mode == "full" else 0)
+
+
+def kernel_source_hash():
+    """SHA-256 over csrc/*.hip and *.h; tools/profile_step.py stores the same value next to
+    the counters it collects."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, PKG, "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")):
+            h.update(fn.encode())
+            with open(os.path.join(csrc, fn), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def recorded_counters(B, D, N):
+    """profiles/counters.json (rocprofv3 PMC summary written by tools/profile_step.py) if it was
+    measured on exactly these kernel sources and this batch shape, else None."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        with open(path) as f:
+            c = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if c.get("source_sha256") != kernel_source_hash():
+        return None
+    if c.get("workload") != "B%d:D%d:N%d" % (B, D, N):
+        return None
+    return c
+
+
 def cpu_baseline(batch, N, D):
     """The oracle (a C port of the reference algorithm; the reference itself cannot be
-    built in this image) timed on this box's host cores on the same inputs."""
+    built in this image) timed on this box's host cores on a bounded sample of the step's
+    inputs."""
     from oracle import tpo
-    import numpy as np
     # one GPU's share of the host is 16 cores on the measurement boxes: stay within it
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     nthreads = max(1, min(cores, 16))
-    B = batch["control_points"].shape[0]
+    B = min(batch["control_points"].shape[0], 1024)
 
     def run(n, nthreads):
         return tpo.time_joint_batch(batch["knots"][:n], batch["control_points"][:n],
@@ -76,9 +124,67 @@ def cpu_baseline(batch, N, D):
     return {
         "value": round(statistics.median(rates), 1), "unit": "paths/s", "cores": nthreads,
         "kind": "port",
-        "sample": "%d of the step's %d paths x3 on %d OpenMP threads (median); single thread "
-                  "on %d paths: %.1f paths/s" % (B, B, nthreads, n1, single),
+        "sample": "the first %d paths of the step's batch x3 on %d OpenMP threads (median); "
+                  "single thread on %d paths: %.1f paths/s" % (B, nthreads, n1, single),
         "single_thread_paths_per_s": round(single, 1),
+    }
+
+
+def roofline_block(kernels, dominant_ms, B, D, N, P, ms_per_step):
+    """kernels: {name: (mean ms, launches)} from the engine's HIP events. The HBM roofline of
+    the dominant kernel as the contract asks, plus what actually limits each kernel."""
+    dom = max(kernels.items(), key=lambda kv: kv[1][0])
+    # k_sweep is timed live over the K timed steps; should another kernel ever be the longest
+    # (tiny --samples), its duration comes from the separate pass
+    dom_ms = dominant_ms if (dom[0] == "k_sweep" and dominant_ms > 0) else dom[1][0]
+    alg = algorithmic_bytes_per_path(D, N, P) * B          # bytes per launch (B paths)
+    achieved = alg / (dom_ms * 1e-3) / 1e9
+    rec = recorded_counters(B, D, N)
+    traffic = step_traffic = step_frac = valu = None
+    per_kernel = {}
+    for name, (ms, n) in kernels.items():
+        if n == 0:
+            continue
+        per_kernel[name] = {"ms": round(ms, 4)}
+    if rec:
+        rk = rec["kernels"]
+        traffic = rk.get(dom[0], {}).get("hbm_bytes")
+        step_traffic = sum(k.get("hbm_bytes", 0) for k in rk.values())
+        step_frac = round(step_traffic / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+        for name, k in rk.items():
+            e = per_kernel.setdefault(name, {"ms": round(k.get("avg_us", 0.0) / 1e3, 4)})
+            ms = e["ms"] or k.get("avg_us", 0.0) / 1e3
+            if "hbm_bytes" in k and ms > 0:
+                e["hbm_bytes"] = k["hbm_bytes"]
+                e["hbm_frac"] = round(k["hbm_bytes"] / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)
+            if "valu_insts" in k and ms > 0:
+                e["valu_frac"] = round(k["valu_insts"] * 64 / (ms * 1e-3) / VALU_PEAK_LANE_OPS, 4)
+            if "valu_busy_pct" in k:
+                e["valu_busy_pct"] = k["valu_busy_pct"]
+            hb, vb = e.get("hbm_frac", 0.0), e.get("valu_busy_pct", 0.0) / 100.0
+            e["limiter"] = ("fp64 VALU issue" if vb >= 0.6 else
+                            "HBM bandwidth" if hb >= 0.5 else
+                            "dependent-instruction latency (neither VALU nor HBM saturated)")
+        d = rk.get(dom[0], {})
+        if "valu_insts" in d:
+            valu = {"kernel": dom[0], "insts_per_launch": d["valu_insts"],
+                    "lane_ops_per_s": round(d["valu_insts"] * 64 / (dom_ms * 1e-3), 1),
+                    "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                    "frac": round(d["valu_insts"] * 64 / (dom_ms * 1e-3) / VALU_PEAK_LANE_OPS, 4),
+                    "busy_pct": d.get("valu_busy_pct"),
+                    "note": "SQ_INSTS_VALU x 64 lanes / kernel time against the fp64 vector issue "
+                            "peak (one wave64 instruction per SIMD per 4 cycles)"}
+    return {
+        "bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+        "kernel_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": alg,
+        "limiter": per_kernel.get(dom[0], {}).get("limiter"),
+        "step_traffic": step_traffic, "step_hbm_frac": step_frac, "valu": valu,
+        "counters": ({"file": "profiles/counters.json", "tag": rec["tag"],
+                      "source_sha256": rec["source_sha256"][:16]} if rec else
+                     "profiles/counters.json was not measured on these kernel sources / this "
+                     "batch shape: traffic and valu are null (tools/profile_step.py refreshes it)"),
+        "kernels": per_kernel,
     }
 
 
@@ -87,14 +193,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--paths-per-gpu", type=int, default=1024)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="configs1",
+                    help="configs1: 1024 paths per GPU (BASELINE.json configs[1]); configs2: 8192 "
+                         "paths per GPU (configs[2], 65536 over 8 GPUs)")
+    ap.add_argument("--paths-per-gpu", type=int, default=0, help="override the workload's batch")
     ap.add_argument("--dofs", type=int, default=7)
     ap.add_argument("--samples", type=int, default=2000)
+    ap.add_argument("--gather", choices=("profile", "full"), default="profile",
+                    help="multi-GPU payload: the timing profile (t, sd, sdd), or q as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
@@ -127,26 +238,33 @@ def main():
         if distributed:
             dist.barrier()
 
-    B, D, N = args.paths_per_gpu, args.dofs, args.samples
+    B = args.paths_per_gpu if args.paths_per_gpu > 0 else WORKLOADS[args.workload]
+    D, N = args.dofs, args.samples
     total_paths = B * world
     lo, hi = shd.shard_bounds(total_paths, world, rank)
-    batch = syn.make_joint_batch(hi - lo, D, N, first_path_index=lo)
+    assert hi - lo == B
+    batch = syn.make_joint_batch(B, D, N, first_path_index=lo)
     P = batch["control_points"].shape[1]
     E = eng.Engine(dev_index)
     E.reserve(B, N, 2 * D)
     inp = eng.upload_joint_batch(batch, dev)
-    # timing profile packed as [3][B][N] = (t, sd, sdd) so that the multi-GPU collection is ONE
-    # gather per batch (s is not sent: it is the arithmetic sequence s_start + i*ds of
-    # time_optimal_path_timing.cc:540-547, which the root rebuilds from per-path scalars);
-    # two output buffers, so that the gather of batch k (rank 0's inbound xGMI links)
-    # overlaps the solve of batch k+1
-    G = shd.PipelinedGather((3, B, N), torch.float64, dev, depth=2)
-    shared = eng.alloc_joint_outputs(B, N, D, dev)
+    # Gather payload, packed so that the multi-GPU collection is ONE gather per batch:
+    #   profile: [3][B][N] = (t, sd, sdd)            48 KB/path at N = 2000
+    #   full:    [3 + D][B][N]-sized block = (t, sd, sdd | q [B][N][D])   104 KB/path at D = 7
+    # (s is never sent: it is the arithmetic sequence s_start + i*ds of
+    # time_optimal_path_timing.cc:540-547, which the root rebuilds from per-path scalars.)
+    # Two buffers, so that the gather of batch k (rank 0's inbound xGMI links) overlaps the solve
+    # of batch k+1.
+    rows = 3 + (D if args.gather == "full" else 0)
+    G = shd.PipelinedGather((rows, B, N), torch.float64, dev, depth=2)
+    shared = eng.alloc_joint_outputs(B, N, D, dev, with_q=(args.gather != "full"))
     outs = []
     for slot in range(2):
         o = dict(shared)
         p = G.send[slot]
         o["time"], o["sd"], o["sdd"] = p[0], p[1], p[2]
+        if args.gather == "full":
+            o["q"] = p[3:].view(B, N, D)          # the engine writes q straight into the payload
         outs.append(o)
     counter = [0]
 
@@ -161,8 +279,6 @@ def main():
         step()
     G.drain()
     torch.cuda.synchronize()
-    out = outs[0]
-    ok = int((out["status"] == 0).sum())
 
     timing = not args.no_kernel_timing
     E.profile_reset()
@@ -179,6 +295,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     E.profile_enable(False)
+    # every path of the LAST timed step must have been solved (status is rewritten by each step)
+    ok = int((outs[(counter[0] - 1) % 2]["status"] == 0).sum()) if counter[0] else 0
     dominant_ms = E.profile_mean_ms(eng.KERNEL_SWEEP)[0] if timing else 0.0
     if timing and rank == 0:
         # the other kernels' durations, outside the timed region (events around every kernel
@@ -198,60 +316,59 @@ def main():
     elapsed = float(el.item())
     solved = int(okt.item())
 
+    failed = args.steps > 0 and solved != total_paths
     if rank == 0:
         kernels = E.profile_summary() if timing else {}
-        ms_per_step = elapsed / args.steps * 1e3
+        ms_per_step = elapsed / max(args.steps, 1) * 1e3
         value = total_paths * args.steps / elapsed
-        # dominant kernel = the one with the largest mean duration
-        roofline = None
-        if kernels:
-            dom = max(kernels.items(), key=lambda kv: kv[1][0])
-            # k_sweep is timed live over the K timed steps; should another kernel ever be the
-            # longest (tiny --samples), its duration comes from the separate pass
-            dom_ms = dominant_ms if dom[0] == "k_sweep" else dom[1][0]
-            alg = algorithmic_bytes_per_path(D, N, P) * B      # bytes per launch (B paths)
-            achieved = alg / (dom_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    key = "%s:B%d:D%d:N%d" % (dom[0], B, D, N)
-                    traffic = tj.get(key)
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "hbm", "kernel": dom[0], "achieved": round(achieved, 3),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                        "kernel_ms": round(dom_ms, 4),
-                        "algorithmic_bytes_per_launch": alg,
-                        "all_kernels_ms": {k: round(v[0], 4) for k, v in kernels.items()}}
+        roofline = roofline_block(kernels, dominant_ms, B, D, N, P, ms_per_step) if kernels else None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(batch, N, D)
+        named = [k for k, v in WORKLOADS.items() if v == B]
+        if named and D == 7 and N == 2000:
+            idx = 1 if named[0] == "configs1" else 2
+            what = "BASELINE.json configs[%d]" % idx
+            if idx == 2 and world != 8:
+                what += "'s per-GPU share (8192 of 65536 paths; the config itself needs 8 GPUs)"
+            if idx == 1 and world > 1:
+                what += " replicated per GPU (weak scaling; configs[2] is --workload configs2)"
+        else:
+            what = "custom shape (not a BASELINE.json config)"
+        gb = gather_bytes_per_path(args.gather if distributed else "none", D, N)
         line = {
             "metric": baseline_metric(),
             "value": round(value, 1), "unit": "paths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: %d random %d-DOF joint-space "
-                                   "B-spline paths per GPU, %d s-samples each (10 waypoints, "
-                                   "%d control points), inputs resident in HBM" % (B, D, N, P),
+            "config": {"workload": "%s: %d random %d-DOF joint-space B-spline paths per GPU, %d "
+                                   "s-samples each (10 waypoints, %d control points), inputs "
+                                   "resident in HBM" % (what, B, D, N, P),
                        "paths_per_gpu": B, "total_paths": total_paths, "num_dofs": D,
                        "num_samples": N, "solved_paths": solved,
-                       "gather": ("one RCCL gather of the packed timing profile "
-                                  "(t,sd,sdd: 3*N*8 B/path; s = s_start + i*ds is rebuilt on the root) to rank 0 per step, overlapped "
-                                  "with the next step's solve (double-buffered), all inside "
-                                  "the timed region"
-                                  if distributed else "none (single GPU)")},
+                       "gather": {"mode": args.gather if distributed else "none (single GPU)",
+                                  "bytes_per_path": gb,
+                                  "bytes_into_rank0_per_step": gb * B * (world - 1),
+                                  "what": ("ONE RCCL gather per step of the packed payload "
+                                           "(t, sd, sdd%s; s = s_start + i*ds is rebuilt on the "
+                                           "root; qd, qdd%s stay on the producing GPU) to rank 0, "
+                                           "overlapped with the next step's solve "
+                                           "(double-buffered), all inside the timed region"
+                                           % ((", q", "") if args.gather == "full" else ("", ", q")))
+                                  if distributed else None}},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
+        if failed:
+            print("bench.py: %d of %d paths solved in the last timed step" % (solved, total_paths),
+                  file=sys.stderr)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

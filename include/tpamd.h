@@ -30,13 +30,14 @@
 extern "C" {
 #endif
 
-#define TPAMD_VERSION 100
+#define TPAMD_VERSION 200
 
 /* call-level errors */
 #define TPAMD_E_INVALID_ARGUMENT (-1)
 #define TPAMD_E_HIP (-2)
 #define TPAMD_E_UNSUPPORTED (-3)
 #define TPAMD_E_NO_DEVICE (-4)
+#define TPAMD_E_STALE (-5) /* engine-held state belongs to a different solve */
 
 /* per-path status (status[b]); 0 = solved. Codes follow the reference's checks:
  * SetupProblem (time_optimal_path_timing.cc:165-193), IsSetupValid (:554-576),
@@ -212,16 +213,18 @@ int tpamd_find_max_sd2_host(tpamd_engine *engine, int num_lps, int num_rows,
 /* ------------------------------------------------------------------------
  * s(t) query: batched TimeOptimalPathProfile::GetPathParameterAndDerivatives
  * (time_optimal_path_timing.cc:1549-1627) on solved profiles. For each path b
- * and query k: t_query[b][k] -> s, sd, sdd, ok [B][K]. time/s/sd are the [B][N]
- * outputs of the LAST solve on this engine (its squared velocities sd2_ and the
- * per-path ds, s_start, s_end are still held in the engine workspace, so call
- * this before the next solve). status may be NULL. Device pointers.
+ * and query k: t_query[b][k] -> s, sd, sdd, ok [B][K]. time/s/sd/sd2 are the [B][N]
+ * outputs of ONE solve (tpamd_path_outputs.time/.s/.sd/.sd2); the per-path ds, s_start and
+ * s_end are recovered from the s rows. sd2 may be NULL: the engine then uses the copy of
+ * sd2_ it keeps from its LAST solve, and returns TPAMD_E_STALE unless `time` is that solve's
+ * output array and the shape matches (a later solve into other buffers invalidates it).
+ * Every path has num_samples samples (no ragged batches). status may be NULL. Device pointers.
  * ------------------------------------------------------------------------ */
 int tpamd_query_device(tpamd_engine *engine, int num_paths, int num_samples,
                        int num_queries, const double *time, const double *s,
-                       const double *sd, const int32_t *status, const double *t_query,
-                       double *out_s, double *out_sd, double *out_sdd, int32_t *ok,
-                       void *hip_stream);
+                       const double *sd, const double *sd2, const int32_t *status,
+                       const double *t_query, double *out_s, double *out_sd, double *out_sdd,
+                       int32_t *ok, void *hip_stream);
 
 /* ------------------------------------------------------------------------
  * Uniform-in-time resample: PathTimingTrajectory::ResampleEquidistantlyInTime

@@ -28,7 +28,7 @@ def test_header_symbols_are_all_exported(eng):
     lib = eng.load_library()
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.tpamd_version() == 100
+    assert lib.tpamd_version() == 200
     assert lib.tpamd_error_string(7).decode().startswith("could not connect")
 
 

@@ -1,0 +1,213 @@
+"""GPU tests of the BASELINE.json configurations at their stated shapes, one GPU's share at a
+time, through the same sharding code bench.py uses (sharding.shard_bounds /
+balanced_bounds + PipelinedGather at world size 1):
+
+  configs[2]  65536 x 7-DOF x 2000 over 8 GPUs  -> rank share 8192 x 7 x 2000
+  configs[4]  mixed 6/7/14-DOF, 500..4000 samples per path, balanced by sum N*C^2
+
+plus the engine-state contracts of the C-ABI (stateful query, per-device setup).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import PKG_NAME
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on an MI355X")
+    eng = importlib.import_module(PKG_NAME + ".engine")
+    syn = importlib.import_module(PKG_NAME + ".synthetic")
+    shd = importlib.import_module(PKG_NAME + ".sharding")
+    from oracle import tpo
+    return dict(torch=torch, eng=eng, syn=syn, shd=shd, tpo=tpo, E=eng.Engine(0), dev="cuda:0")
+
+
+def test_config2_one_gpu_share_through_the_sharded_pipeline(env):
+    """configs[2]: rank 5 of 8 solves its contiguous block of the 65536-path batch into the
+    double-buffered gather payload, twice (both pipeline slots). Full-size properties on every
+    path (on the device), bit-parity with the oracle on a strided subset."""
+    torch, eng, syn, shd, tpo, E = (env[k] for k in ("torch", "eng", "syn", "shd", "tpo", "E"))
+    total, world, rank, D, N = 65536, 8, 5, 7, 2000
+    lo, hi = shd.shard_bounds(total, world, rank)
+    B = hi - lo
+    assert (B, lo) == (8192, 5 * 8192)
+    batch = syn.make_joint_batch(B, D, N, first_path_index=lo)
+    inp = eng.upload_joint_batch(batch, env["dev"])
+    G = shd.PipelinedGather((3, B, N), torch.float64, env["dev"], depth=2)
+    assert G.world == 1
+    shared = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    outs = []
+    for slot in range(2):
+        o = dict(shared)
+        o["time"], o["sd"], o["sdd"] = G.send[slot][0], G.send[slot][1], G.send[slot][2]
+        outs.append(o)
+    for k in range(2):
+        G.buffer(k)
+        E.time_joint_paths(inp, outs[k], N)
+        G.launch(k)
+    G.drain()
+    torch.cuda.synchronize()
+    r0, r1 = G.result(0), G.result(1)
+    assert tuple(r0.shape) == (1, 3, B, N)
+    assert torch.equal(r0, r1)                      # the two slots hold the same solve
+    out = outs[0]
+    assert int((out["status"] != 0).sum()) == 0     # every path of the shard solved
+    t, s, sd, sdd = out["time"], out["s"], out["sd"], out["sdd"]
+    assert bool(torch.isfinite(r0).all())
+    assert bool((t[:, 1:] >= t[:, :-1]).all()) and bool((t[:, 0] == 0).all())
+    assert bool((sd >= 0).all()) and bool((sd[:, 0] == 0).all()) and bool((sd[:, -1] == 0).all())
+    vmax = inp["max_velocity"][:, None, :]
+    amax = inp["max_acceleration"][:, None, :]
+    assert bool((out["qd"].abs() <= 0.8 * vmax * (1 + 1e-9) + 1e-12).all())
+    assert bool((out["qdd"].abs() <= amax).all())
+    delta = torch.from_numpy(batch["delta"]).to(env["dev"])
+    assert torch.equal(s[:, -1], delta * (N - 1)) and bool((s[:, 0] == 0).all())
+    assert bool(((out["q"][:, 0] - inp["control_points"][:, 0]).abs() <= 1e-12).all())
+    lei = out["last_extremal_index"]
+    assert bool((lei >= 1).all()) and bool((lei <= N - 2).all())
+    # strided subset against the oracle, every output bit for bit
+    sel = np.arange(0, B, 331)
+    ref = tpo.time_joint_batch(batch["knots"][sel], batch["control_points"][sel],
+                               batch["vmax"][sel], batch["amax"][sel], batch["path_start"][sel],
+                               batch["delta"][sel], N, nthreads=8)
+    assert (ref["status"] == 0).all()
+    sel_d = torch.from_numpy(sel).to(env["dev"])
+    for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+        np.testing.assert_array_equal(out[k][sel_d].cpu().numpy(), ref["t" if k == "time" else k],
+                                      err_msg=k)
+    np.testing.assert_array_equal(lei[sel_d].cpu().numpy(), ref["last_extremal_index"])
+
+
+def test_config4_mixed_dof_ragged_share_every_path_matches_its_oracle_run(env):
+    """configs[4] at its stated shape: joint counts from {6, 7, 14}, 500..4000 samples per
+    path, partitioned over 8 ranks by sum N*C^2 (sharding.balanced_bounds); rank 3's share is
+    bucketed by (D, ceil(N/512)), solved bucket by bucket, and EVERY path is compared with the
+    oracle run on that path alone with its own sample count."""
+    torch, eng, syn, shd, tpo, E = (env[k] for k in ("torch", "eng", "syn", "shd", "tpo", "E"))
+    total, world, rank = 1536, 8, 3
+    dofs, samples = syn.mixed_batch_shape(total)
+    assert set(np.unique(dofs)) == {6, 7, 14} and samples.min() >= 500 and samples.max() <= 4000
+    costs = samples.astype(np.float64) * (2.0 * dofs) ** 2
+    bounds = shd.balanced_bounds(costs, world)
+    assert bounds[0][0] == 0 and bounds[-1][1] == total
+    assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+    share_costs = [costs[a:b].sum() for a, b in bounds]
+    assert max(share_costs) <= 1.15 * (costs.sum() / world)          # balanced by cost, not count
+    lo, hi = bounds[rank]
+    groups = syn.mixed_batch_groups(dofs[lo:hi], samples[lo:hi])
+    assert {k[0] for k in groups} == {6, 7, 14}
+    checked = 0
+    for (D, stride), pos in groups.items():
+        gidx = lo + pos
+        ns = samples[gidx]
+        b = syn.make_mixed_group(gidx, D, ns, stride)
+        inp = eng.upload_joint_batch(b, env["dev"])
+        inp["num_samples_per_path"] = torch.from_numpy(ns).to(env["dev"])
+        out = eng.alloc_joint_outputs(len(pos), stride, D, env["dev"])
+        for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd"):
+            out[k].fill_(-7.0)
+        E.time_joint_paths(inp, out, stride)
+        torch.cuda.synchronize()
+        st = out["status"].cpu().numpy()
+        got = {k: out[k].cpu().numpy() for k in ("time", "s", "sd", "sdd", "q", "qd", "qdd")}
+        lei = out["last_extremal_index"].cpu().numpy()
+        for i, n in enumerate(ns):
+            one = [b[k][i:i + 1] for k in ("knots", "control_points", "vmax", "amax",
+                                            "path_start", "delta")]
+            ref = tpo.time_joint_batch(*one, int(n), nthreads=1)
+            assert st[i] == ref["status"][0] == 0, (D, stride, i, st[i])
+            assert lei[i] == ref["last_extremal_index"][0]
+            for k in got:
+                np.testing.assert_array_equal(got[k][i, :n], ref["t" if k == "time" else k][0],
+                                              err_msg="%s D=%d n=%d" % (k, D, n))
+                assert (got[k][i, n:] == -7.0).all(), "wrote past the path's sample count"
+            checked += 1
+    assert checked == hi - lo and checked >= 150
+
+
+def test_query_uses_the_solve_it_is_given_not_the_last_one(env):
+    """include/tpamd.h tpamd_query_device: with an explicit sd2 the query is stateless; without
+    it the engine refuses (TPAMD_E_STALE) once another solve of the same shape has run."""
+    torch, eng, syn, tpo, E = (env[k] for k in ("torch", "eng", "syn", "tpo", "E"))
+    D, N, B, K = 7, 400, 4, 65
+    f = dict(dtype=torch.float64, device=env["dev"])
+
+    def solve(first):
+        b = syn.make_joint_batch(B, D, N, first_path_index=first)
+        inp = eng.upload_joint_batch(b, env["dev"])
+        out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+        out["sd2"] = torch.empty(B, N, **f)
+        E.time_joint_paths(inp, out, N)
+        torch.cuda.synchronize()
+        return b, out
+
+    b1, o1 = solve(100)
+    rng = np.random.default_rng(3)
+    tq = np.sort(rng.uniform(-0.1, o1["time"][:, -1:].cpu().numpy() + 0.1, (B, K)), axis=1)
+    tq_d = torch.from_numpy(tq).to(env["dev"])
+
+    def query(out, sd2):
+        qs, qsd, qsdd = (torch.empty(B, K, **f) for _ in range(3))
+        ok = torch.zeros(B, K, dtype=torch.int32, device=env["dev"])
+        E.query(out["time"], out["s"], out["sd"], out["status"], tq_d, qs, qsd, qsdd, ok, sd2=sd2)
+        torch.cuda.synchronize()
+        return qs.cpu().numpy(), qsd.cpu().numpy(), qsdd.cpu().numpy()
+
+    first = query(o1, None)                     # engine state still belongs to solve 1
+    b2, o2 = solve(900)                         # same shape, different paths, other buffers
+    assert not torch.equal(o1["time"], o2["time"])
+    with pytest.raises(eng.TpamdError, match="different solve"):
+        query(o1, None)
+    again = query(o1, o1["sd2"])                # stateless form: still solve 1's answer
+    for a, c in zip(first, again):
+        np.testing.assert_array_equal(a, c)
+    for i in range(B):                          # and it is the oracle's answer
+        q_, q1, q2 = tpo.joint_sample_path(b1["knots"][i], b1["control_points"][i], 0.0,
+                                           b1["delta"][i], N)
+        rows = tpo.joint_constraint_setup(q1, q2, b1["vmax"][i], b1["amax"][i])
+        p = tpo.Profile(N, 2 * D)
+        p.set_max_loops(10 * N)
+        assert p.setup(*rows, 0.0, b1["delta"][i] * (N - 1)) == 0 and p.optimize() == 0
+        ref = np.array([p.query(x)[1:] for x in tq[i]])
+        for k in range(3):
+            np.testing.assert_array_equal(again[k][i], ref[:, k])
+    query(o2, None)                             # the last solve can still use the short form
+
+
+def test_tiny_batches_do_not_read_past_the_workspace(env):
+    """One path, 14 joints, 3..40 samples: the sweep's 32-record tile prefetch reaches past
+    the path's last record; the workspace keeps a tile of slack behind the records
+    (tpamd_capi.hip carve_workspace). A fresh engine so that nothing larger was reserved."""
+    torch, eng, syn, tpo = (env[k] for k in ("torch", "eng", "syn", "tpo"))
+    E = eng.Engine(0)
+    for D in (14, 7):
+        for N in (3, 4, 7, 31, 32, 33, 40):
+            b = syn.make_joint_batch(1, D, N)
+            inp = eng.upload_joint_batch(b, env["dev"])
+            out = eng.alloc_joint_outputs(1, N, D, env["dev"])
+            E.time_joint_paths(inp, out, N)
+            torch.cuda.synchronize()
+            ref = tpo.time_joint_batch(b["knots"], b["control_points"], b["vmax"], b["amax"],
+                                       b["path_start"], b["delta"], N)
+            assert out["status"].item() == ref["status"][0], (D, N)
+            if ref["status"][0] == 0:
+                for k in ("time", "sd", "sdd", "qd", "qdd"):
+                    np.testing.assert_array_equal(out[k].cpu().numpy(),
+                                                  ref["t" if k == "time" else k])
+    E.close()
+
+
+def test_engine_leaves_the_callers_device_current(env):
+    torch, eng = env["torch"], env["eng"]
+    before = torch.cuda.current_device()
+    E2 = eng.Engine(0)
+    E2.reserve(8, 100, 14)
+    assert torch.cuda.current_device() == before
+    E2.close()

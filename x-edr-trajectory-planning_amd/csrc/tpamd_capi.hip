@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -64,9 +65,16 @@ struct tpamd_engine {
   size_t rows_bytes = 0;
   Workspace ws{};
   int last_B = 0, last_N = 0;
+  const double *last_time = nullptr;   // out->time of the last solve (tpamd_query_device's check)
   int profile = 0;             // 0 off, 1 every kernel, 2 the sweep kernel only
   bool force_generic = false;  // TPAMD_FORCE_GENERIC=1: A/B the specialised kernels
+  // Event timing: pending (start, stop) pairs are folded into acc_ms/acc_n and their events
+  // recycled through `pool` once kMaxPendingEvents are outstanding, so a long profiled run
+  // holds a bounded number of HIP events.
   std::vector<EventPair> events;
+  std::vector<EventPair> pool;
+  double acc_ms[KI_COUNT] = {};
+  int acc_n[KI_COUNT] = {};
 };
 
 namespace {
@@ -90,7 +98,9 @@ size_t carve_workspace(char *base, int B, int N, int C, Workspace *ws) {
   w.delta = (double *)take(nb * 8);
   w.err_bits = (uint32_t *)take(nb * 4);
   w.lim = (double *)take(nb * 2 * C * 8);
-  w.q12 = (double *)take(ns * (C + 2) * 8);
+  // + one tile of records: the sweep's tile prefetch always loads 32 whole records, so the
+  // last path's partial tile reads up to 31 records past its end (tpamd_sweep_joint.h)
+  w.q12 = (double *)take((ns + kTileSamples) * (C + 2) * 8);
   w.m0 = (double *)take(ns * 8);
   w.z0 = (double *)take(ns * 8);
   w.X0 = (double *)take(ns * 8);
@@ -145,6 +155,23 @@ int ensure_rows(tpamd_engine *e, size_t need) {
   return 0;
 }
 
+constexpr size_t kMaxPendingEvents = 512;
+
+// Fold every pending event pair into the per-kernel sums (waits for the recorded work) and
+// hand the events back to the pool.
+void fold_events(tpamd_engine *e) {
+  for (auto &ev : e->events) {
+    float ms = 0.f;
+    if (hipEventSynchronize(ev.stop) == hipSuccess &&
+        hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) {
+      e->acc_ms[ev.kernel] += ms;
+      e->acc_n[ev.kernel]++;
+    }
+    e->pool.push_back(ev);
+  }
+  e->events.clear();
+}
+
 struct Timer {
   tpamd_engine *e;
   hipStream_t st;
@@ -153,12 +180,17 @@ struct Timer {
   bool on;
   Timer(tpamd_engine *e_, hipStream_t st_, int k)
       : e(e_), st(st_), kernel(k), on(e_->profile == 1 || (e_->profile == 2 && k == KI_SWEEP)) {
-    if (on) {
-      (void)hipEventCreate(&ev.start);
-      (void)hipEventCreate(&ev.stop);
-      ev.kernel = kernel;
-      (void)hipEventRecord(ev.start, st);
+    if (!on) return;
+    if (e->events.size() >= kMaxPendingEvents) fold_events(e);
+    if (!e->pool.empty()) {
+      ev = e->pool.back();
+      e->pool.pop_back();
+    } else if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) {
+      on = false;
+      return;
     }
+    ev.kernel = kernel;
+    (void)hipEventRecord(ev.start, st);
   }
   ~Timer() {
     if (on) {
@@ -168,43 +200,73 @@ struct Timer {
   }
 };
 
-int lds_limit_set = 0;
+// Makes e->device current for the duration of an entry point and restores the caller's
+// device afterwards (the caller may be PyTorch with another device current).
+struct DeviceScope {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    err = (prev == device) ? hipSuccess : hipSetDevice(device);
+    if (prev == device) prev = -1;   // nothing to restore
+  }
+  ~DeviceScope() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define TPAMD_ON_DEVICE(e)          \
+  DeviceScope device_scope_((e)->device); \
+  HIPCHK(device_scope_.err)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: it is set
+// for every kernel that can ask for more than 64 KB of LDS, once per device ordinal, when the
+// first engine on that device is created (thread-safe; a failure is reported).
+constexpr int kMaxDevices = 64;
+std::mutex g_config_mutex;
+bool g_device_configured[kMaxDevices] = {};
 
 template <typename K>
-void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+hipError_t allow_big_lds(K kernel, int bytes = 160 * 1024) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-void configure_kernels_once() {
-  if (lds_limit_set) return;
-  lds_limit_set = 1;
-  allow_big_lds(k_sample_lp_joint<1, 0>);
-  allow_big_lds(k_sample_lp_joint<1, 6>);
-  allow_big_lds(k_sample_lp_joint<1, 7>);
-  allow_big_lds(k_sample_lp_joint<1, 14>);
-  allow_big_lds(k_lp_rows<1>);
-  allow_big_lds(k_lp_rows<2>);
-  allow_big_lds(k_sweep<JointSource>);
-  allow_big_lds(k_sweep<GenericSource>);
-  allow_big_lds(k_sweep_joint<6, 1>);
-  allow_big_lds(k_sweep_joint<7, 1>);
-  allow_big_lds(k_sweep_joint<14, 1>);
-  allow_big_lds(k_sweep_joint<6, 2>);
-  allow_big_lds(k_sweep_joint<7, 2>);
-  allow_big_lds(k_sweep_joint<14, 2>);
-  allow_big_lds(k_sweep_joint<3, 2>);
-  allow_big_lds(k_sweep_joint<4, 2>);
-  allow_big_lds(k_sweep_joint<5, 2>);
-  allow_big_lds(k_sweep_joint<8, 2>);
-  allow_big_lds(k_sample_lp_joint<1, 3>);
-  allow_big_lds(k_sample_lp_joint<1, 4>);
-  allow_big_lds(k_sample_lp_joint<1, 5>);
-  allow_big_lds(k_sample_lp_joint<1, 8>);
-  allow_big_lds(k_sweep_joint<6, 2, 2>);
-  allow_big_lds(k_sweep_joint<7, 2, 2>);
-  allow_big_lds(k_cartesian_lp<1, 6>);
-  allow_big_lds(k_cartesian_lp<1, 7>);
+// The current device must be `device`.
+int configure_kernels_for_device(int device) {
+  if (device < 0 || device >= kMaxDevices) return TPAMD_E_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g_config_mutex);
+  if (g_device_configured[device]) return 0;
+#define TPAMD_BIG_LDS(...) HIPCHK(allow_big_lds(__VA_ARGS__))
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 0>);
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 3>);
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 4>);
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 5>);
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 6>);
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 7>);
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 8>);
+  TPAMD_BIG_LDS(k_sample_lp_joint<1, 14>);
+  TPAMD_BIG_LDS(k_lp_rows<1>);
+  TPAMD_BIG_LDS(k_lp_rows<2>);
+  TPAMD_BIG_LDS(k_sweep<JointSource>);
+  TPAMD_BIG_LDS(k_sweep<GenericSource>);
+  TPAMD_BIG_LDS(k_sweep_joint<6, 1>);
+  TPAMD_BIG_LDS(k_sweep_joint<7, 1>);
+  TPAMD_BIG_LDS(k_sweep_joint<14, 1>);
+  TPAMD_BIG_LDS(k_sweep_joint<3, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<4, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<5, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<6, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<7, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<8, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<14, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<6, 2, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<7, 2, 2>);
+  TPAMD_BIG_LDS(k_cartesian_lp<1, 6>);
+  TPAMD_BIG_LDS(k_cartesian_lp<1, 7>);
+  TPAMD_BIG_LDS(k_resample_skip, 128 * 1024);   // int[N], N <= 32768, next to 8 B static
+#undef TPAMD_BIG_LDS
+  g_device_configured[device] = true;
+  return 0;
 }
 
 // The sweep launch: joint-space batches with D in {3..8, 14} take the specialised kernel
@@ -334,6 +396,7 @@ const char *tpamd_error_string(int code) {
     case TPAMD_E_HIP: return "HIP runtime error";
     case TPAMD_E_UNSUPPORTED: return "unsupported size";
     case TPAMD_E_NO_DEVICE: return "no HIP device";
+    case TPAMD_E_STALE: return "engine state belongs to a different solve";
     case TPAMD_PATH_INFEASIBLE_BOUNDS: return "infeasible bounds: no upper > lower at a sample";
     case TPAMD_PATH_S_RANGE: return "s_start must be < s_end";
     case TPAMD_PATH_SD_START_NEGATIVE: return "sd_start must be >= 0";
@@ -356,7 +419,10 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
     return TPAMD_E_NO_DEVICE;
   }
   if (device_ordinal < 0 || device_ordinal >= count) return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(device_ordinal));
+  DeviceScope scope(device_ordinal);
+  HIPCHK(scope.err);
+  const int rc = configure_kernels_for_device(device_ordinal);
+  if (rc) return rc;
   tpamd_engine *e = new (std::nothrow) tpamd_engine();
   if (!e) return TPAMD_E_HIP;
   e->device = device_ordinal;
@@ -364,15 +430,15 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
     const char *fg = std::getenv("TPAMD_FORCE_GENERIC");
     e->force_generic = fg && fg[0] == '1';
   }
-  configure_kernels_once();
   *out = e;
   return 0;
 }
 
 void tpamd_engine_destroy(tpamd_engine *e) {
   if (!e) return;
-  (void)hipSetDevice(e->device);
-  for (auto &ev : e->events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
+  DeviceScope scope(e->device);
+  for (auto *v : {&e->events, &e->pool})
+    for (auto &ev : *v) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
   if (e->ws_base) (void)hipFree(e->ws_base);
   if (e->stage_base) (void)hipFree(e->stage_base);
   if (e->rows_base) (void)hipFree(e->rows_base);
@@ -381,7 +447,7 @@ void tpamd_engine_destroy(tpamd_engine *e) {
 
 int tpamd_engine_reserve(tpamd_engine *e, int B, int N, int C) {
   if (!e || B <= 0 || N <= 0 || C <= 0) return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   return ensure_workspace(e, B, N, C);
 }
 
@@ -398,12 +464,12 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
       !in->path_start || !in->delta || !in->sd_start || !in->time_start || !out->time ||
       !out->s || !out->sd || !out->sdd || !out->status)
     return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   hipStream_t st = (hipStream_t)hip_stream;
   const int C = 2 * D;
   int rc = ensure_workspace(e, B, N, C);
   if (rc) return rc;
-  e->last_B = B; e->last_N = N;
+  e->last_B = B; e->last_N = N; e->last_time = out->time;
   e->ws.ns = in->num_samples_per_path;
   e->ws.amax = in->max_acceleration;
   const Workspace &ws = e->ws;
@@ -461,11 +527,11 @@ int tpamd_optimize_rows_device(tpamd_engine *e, const tpamd_rows_batch *bt,
       !in->sd_start || !in->time_start || !out->time || !out->s || !out->sd || !out->sdd ||
       !out->status)
     return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   hipStream_t st = (hipStream_t)hip_stream;
   int rc = ensure_workspace(e, B, N, 1);
   if (rc) return rc;
-  e->last_B = B; e->last_N = N;
+  e->last_B = B; e->last_N = N; e->last_time = out->time;
   e->ws.ns = nullptr;
   const Workspace &ws = e->ws;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 100;
@@ -489,14 +555,14 @@ int tpamd_time_cartesian_paths_device(tpamd_engine *e, const tpamd_cartesian_bat
       !in->delta || !in->sd_start || !in->time_start || !out->time || !out->s || !out->sd ||
       !out->sdd || !out->status)
     return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   hipStream_t st = (hipStream_t)hip_stream;
   const int C = 2 * D + 2;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;
   const bool fused = (D == 6 || D == 7) && !e->force_generic;
   int rc = ensure_workspace(e, B, N, C);
   if (rc) return rc;
-  e->last_B = B; e->last_N = N;
+  e->last_B = B; e->last_N = N; e->last_time = out->time;
   e->ws.ns = nullptr;
   e->ws.amax = in->max_acceleration;
   {
@@ -587,7 +653,7 @@ int tpamd_time_cartesian_paths_host(tpamd_engine *e, const tpamd_cartesian_batch
       !out->sdd || !out->status)
     return TPAMD_E_INVALID_ARGUMENT;
   const size_t B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   for (int pass = 0; pass < 2; pass++) {
     Stage s(pass ? e->stage_base : nullptr);
     double *d_q = s.take<double>(B * N * D), *d_J = s.take<double>(B * N * 6 * D);
@@ -651,7 +717,7 @@ int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
   if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
   const size_t B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples, P = bt->num_points;
   if (bt->num_paths <= 0) return bt->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   for (int pass = 0; pass < 2; pass++) {
     Stage s(pass ? e->stage_base : nullptr);
     double *d_knots = s.take<double>(B * (P + 3)), *d_cp = s.take<double>(B * P * D);
@@ -717,7 +783,7 @@ int tpamd_sample_joint_paths_host(tpamd_engine *e, int num_paths, int num_dofs, 
   if (num_paths <= 0) return num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
   if (num_dofs < 1 || num_samples < 1 || num_points < 3) return TPAMD_E_UNSUPPORTED;
   const size_t B = num_paths, D = num_dofs, N = num_samples, P = num_points;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   for (int pass = 0; pass < 2; pass++) {
     Stage s(pass ? e->stage_base : nullptr);
     double *d_knots = s.take<double>(B * (P + 3)), *d_cp = s.take<double>(B * P * D);
@@ -751,7 +817,7 @@ int tpamd_optimize_rows_host(tpamd_engine *e, const tpamd_rows_batch *bt,
   if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
   const size_t B = bt->num_paths, N = bt->num_samples, C = bt->num_rows;
   if (bt->num_paths <= 0) return bt->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   for (int pass = 0; pass < 2; pass++) {
     Stage s(pass ? e->stage_base : nullptr);
     double *d_a = s.take<double>(B * N * C), *d_b = s.take<double>(B * N * C);
@@ -808,7 +874,7 @@ int tpamd_find_max_sd2_host(tpamd_engine *e, int num, int C, const double *a, co
     return TPAMD_E_INVALID_ARGUMENT;
   if (num == 0) return 0;
   if (C < 1 || C > 64) return TPAMD_E_UNSUPPORTED;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   const size_t n = (size_t)num, nc = n * C;
   for (int pass = 0; pass < 2; pass++) {
     Stage s(pass ? e->stage_base : nullptr);
@@ -842,15 +908,22 @@ int tpamd_find_max_sd2_host(tpamd_engine *e, int num, int C, const double *a, co
 }
 
 int tpamd_query_device(tpamd_engine *e, int B, int N, int K, const double *time, const double *s,
-                       const double *sd, const int32_t *status, const double *t_query,
-                       double *os, double *osd, double *osdd, int32_t *ok, void *hip_stream) {
+                       const double *sd, const double *sd2, const int32_t *status,
+                       const double *t_query, double *os, double *osd, double *osdd, int32_t *ok,
+                       void *hip_stream) {
   if (!e || !time || !s || !sd || !t_query || !os || !osd || !osdd) return TPAMD_E_INVALID_ARGUMENT;
-  if (B != e->last_B || N != e->last_N) return TPAMD_E_INVALID_ARGUMENT;
-  if (B <= 0 || K <= 0) return 0;
-  HIPCHK(hipSetDevice(e->device));
+  if (B < 0 || K < 0 || N < 2) return TPAMD_E_INVALID_ARGUMENT;
+  if (!sd2) {
+    // fall back to the copy of sd2_ the engine keeps from its last solve -- only if that is
+    // the solve these rows came from
+    if (B != e->last_B || N != e->last_N || time != e->last_time) return TPAMD_E_STALE;
+    sd2 = e->ws.sd2;
+  }
+  if (B == 0 || K == 0) return 0;
+  TPAMD_ON_DEVICE(e);
   const size_t total = (size_t)B * K;
   hipLaunchKernelGGL(k_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)hip_stream, B, N, K, time, s, sd, status, e->ws, t_query, os,
+                     (hipStream_t)hip_stream, B, N, K, time, s, sd, sd2, status, t_query, os,
                      osd, osdd, ok);
   HIPCHK(hipGetLastError());
   return 0;
@@ -868,7 +941,7 @@ int resample_device(tpamd_engine *e, const tpamd_resample_args *a, void *hip_str
       !a->max_acceleration || !a->start_sec || !a->out_time || !a->out_s || !a->out_sd ||
       !a->out_sdd || !a->out_q || !a->out_qd || !a->out_qdd || !a->count)
     return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   ResampleParams p;
   p.B = a->num_paths; p.N = a->num_samples; p.D = a->num_dofs; p.max_out = a->max_out;
   p.time = a->time; p.s = a->s; p.sd = a->sd; p.sdd = a->sdd;
@@ -893,7 +966,7 @@ int resample_host(tpamd_engine *e, const tpamd_resample_args *a, bool skip_mode)
   if (!e || !a) return TPAMD_E_INVALID_ARGUMENT;
   if (a->num_paths <= 0) return a->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
   const size_t B = a->num_paths, N = a->num_samples, D = a->num_dofs, M = a->max_out;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   for (int pass = 0; pass < 2; pass++) {
     Stage s(pass ? e->stage_base : nullptr);
     double *d_t = s.take<double>(B * N), *d_s = s.take<double>(B * N), *d_sd = s.take<double>(B * N),
@@ -962,7 +1035,7 @@ int tpamd_resample_skip_host(tpamd_engine *e, const tpamd_resample_args *a) {
 int tpamd_debug_copy_boundary(tpamd_engine *e, int B, int N, double *sd2_max, double *sdd_max,
                               double *sdd_min, double *sd2_zero, uint8_t *type, double *sd2) {
   if (!e || B != e->last_B || N != e->last_N) return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   HIPCHK(hipDeviceSynchronize());
   const size_t n = (size_t)B * N;
   if (sd2_max) HIPCHK(hipMemcpy(sd2_max, e->ws.m, n * 8, hipMemcpyDeviceToHost));
@@ -979,7 +1052,7 @@ int tpamd_debug_copy_boundary(tpamd_engine *e, int B, int N, double *sd2_max, do
 
 int tpamd_debug_copy_diag(tpamd_engine *e, int B, long long *out) {
   if (!e || !out || B != e->last_B) return TPAMD_E_INVALID_ARGUMENT;
-  HIPCHK(hipSetDevice(e->device));
+  TPAMD_ON_DEVICE(e);
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, e->ws.diag, (size_t)B * 16 * 8, hipMemcpyDeviceToHost));
   return 0;
@@ -991,25 +1064,19 @@ void tpamd_profile_enable(tpamd_engine *e, int enable) {
 
 void tpamd_profile_reset(tpamd_engine *e) {
   if (!e) return;
-  (void)hipSetDevice(e->device);
-  for (auto &ev : e->events) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
-  e->events.clear();
+  DeviceScope scope(e->device);
+  fold_events(e);   // recycles the events
+  for (int k = 0; k < KI_COUNT; k++) { e->acc_ms[k] = 0.0; e->acc_n[k] = 0; }
 }
 
 double tpamd_profile_mean_ms(tpamd_engine *e, int kernel_index, int *num_launches) {
   if (num_launches) *num_launches = 0;
-  if (!e) return 0.0;
-  (void)hipSetDevice(e->device);
-  double total = 0.0;
-  int n = 0;
-  for (auto &ev : e->events) {
-    if (ev.kernel != kernel_index) continue;
-    if (hipEventSynchronize(ev.stop) != hipSuccess) continue;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ev.start, ev.stop) == hipSuccess) { total += ms; n++; }
-  }
+  if (!e || kernel_index < 0 || kernel_index >= KI_COUNT) return 0.0;
+  DeviceScope scope(e->device);
+  fold_events(e);
+  const int n = e->acc_n[kernel_index];
   if (num_launches) *num_launches = n;
-  return n ? total / n : 0.0;
+  return n ? e->acc_ms[kernel_index] / n : 0.0;
 }
 
 const char *tpamd_profile_kernel_name(int k) { return (k >= 0 && k < KI_COUNT) ? kKernelNames[k] : ""; }

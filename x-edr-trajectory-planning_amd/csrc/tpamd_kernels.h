@@ -1307,8 +1307,11 @@ __global__ void k_epilogue(int B, int N, int D, const double *rec, const double 
 // GetPathParameterAndDerivatives, time_optimal_path_timing.cc:1549-1627, with
 // SampleIndexFromTime :1497-1524 (the bracket time[k] <= t < time[k+1] is unique
 // for a non-decreasing time array, so a plain binary search finds the same k).
+// sd2_g: the squared velocities sd2_ of the SAME solve that produced time/s/sd. ds_, s_start
+// and s_end are recovered from the s row: s[0] = ds*0 + s_start and s[N-1] = s_end exactly
+// (.cc:540-547), so (s[N-1] - s[0]) / (N-1) repeats the operation that formed ds_ (.cc:540).
 __global__ void k_query(int B, int N, int K, const double *time, const double *s,
-                        const double *sd, const int32_t *status, Workspace ws,
+                        const double *sd, const double *sd2_g, const int32_t *status,
                         const double *tq, double *os, double *osd, double *osdd,
                         int32_t *ok) {
   const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1319,16 +1322,17 @@ __global__ void k_query(int B, int N, int K, const double *time, const double *s
     return;
   }
   const double *tm = time + (size_t)b * N, *sp = s + (size_t)b * N, *sdp = sd + (size_t)b * N,
-               *sd2 = ws.sd2 + (size_t)b * N;
-  const double ds_ = ws.ds[b];
+               *sd2 = sd2_g + (size_t)b * N;
+  const double s_start = sp[0], s_end = sp[N - 1];
+  const double ds_ = (s_end - s_start) / (N - 1);
   const double inv_ds = 1.0 / ds_;
   const double t = tq[o];
   int good = 1;
   double rs, rsd, rsdd;
   if (t <= tm[0]) {
-    rs = ws.s_start[b]; rsd = sdp[0]; rsdd = 0.5 * inv_ds * (sd2[1] - sd2[0]);
+    rs = s_start; rsd = sdp[0]; rsdd = 0.5 * inv_ds * (sd2[1] - sd2[0]);
   } else if (t >= tm[N - 1]) {
-    rs = ws.s_end[b]; rsd = sdp[N - 1]; rsdd = 0.0;
+    rs = s_end; rsd = sdp[N - 1]; rsdd = 0.0;
   } else {
     int lo = 0, hi = N - 1;  // invariant: tm[lo] <= t < tm[hi]
     while (hi - lo > 1) {

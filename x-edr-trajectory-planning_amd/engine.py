@@ -184,7 +184,7 @@ def load_library():
     L.tpamd_find_max_sd2_host.restype = i
     L.tpamd_find_max_sd2_host.argtypes = [vp, i, i] + [vp] * 7
     L.tpamd_query_device.restype = i
-    L.tpamd_query_device.argtypes = [vp, i, i, i] + [vp] * 9 + [vp]
+    L.tpamd_query_device.argtypes = [vp, i, i, i] + [vp] * 10 + [vp]
     L.tpamd_resample_uniform_device.restype = i
     L.tpamd_resample_uniform_device.argtypes = [vp, C.POINTER(_ResampleArgs), vp]
     L.tpamd_resample_uniform_host.restype = i
@@ -345,11 +345,14 @@ class Engine:
                "tpamd_find_max_sd2_host")
         return tuple(o)
 
-    def query(self, time, s, sd, status, t_query, out_s, out_sd, out_sdd, ok=None, stream=None):
+    def query(self, time, s, sd, status, t_query, out_s, out_sd, out_sdd, ok=None, stream=None,
+              sd2=None):
+        """sd2: the solve's squared velocities (outputs["sd2"]); None = the engine's copy from
+        its last solve (TpamdError "stale" if time is not that solve's output)."""
         B, N = time.shape
         K = t_query.shape[1]
         _check(self._lib.tpamd_query_device(self._h, B, N, K, _ptr(time), _ptr(s), _ptr(sd),
-                                            _ptr(status), _ptr(t_query), _ptr(out_s),
+                                            _ptr(sd2), _ptr(status), _ptr(t_query), _ptr(out_s),
                                             _ptr(out_sd), _ptr(out_sdd), _ptr(ok),
                                             _stream_ptr(stream)), "tpamd_query_device")
 

@@ -96,7 +96,7 @@ def fit_joint_splines(waypoints, rounding=0.2):
 
 
 def make_joint_batch(num_paths, num_dofs=7, num_samples=2000, num_waypoints=10,
-                     first_path_index=0, rounding=0.2, safety=0.8):
+                     first_path_index=0, rounding=0.2, safety=0.8, path_indices=None):
     """The batch definition of SURVEY.md section 8(d).
 
     Returns a dict of host numpy arrays:
@@ -105,7 +105,11 @@ def make_joint_batch(num_paths, num_dofs=7, num_samples=2000, num_waypoints=10,
     plus scalars num_samples, safety.
     """
     B, D, W = int(num_paths), int(num_dofs), int(num_waypoints)
-    idx = np.arange(first_path_index, first_path_index + B, dtype=np.uint64)
+    if path_indices is not None:       # explicit path indices (mixed batches) instead of a range
+        idx = np.asarray(path_indices, dtype=np.uint64)
+        assert idx.shape == (B,)
+    else:
+        idx = np.arange(first_path_index, first_path_index + B, dtype=np.uint64)
     u = _splitmix_stream(idx, W * D + 2 * D)
     waypoints = (u[:, :W * D] * 4.0 - 2.0).reshape(B, W, D)
     vmax = 1.0 + u[:, W * D:W * D + D]
@@ -119,6 +123,45 @@ def make_joint_batch(num_paths, num_dofs=7, num_samples=2000, num_waypoints=10,
         sd_start=np.zeros(B), time_start=np.zeros(B),
         num_samples=int(num_samples), safety=float(safety), waypoints=waypoints,
     )
+
+
+MIXED_DOFS = (6, 7, 14)
+MIXED_SAMPLES = (500, 4000)
+MIXED_BUCKET = 512
+
+
+def mixed_batch_shape(num_paths, first_path_index=0):
+    """BASELINE.json configs[4] (SURVEY.md 8d "Config 5"): per path a joint count drawn from
+    {6, 7, 14} and a sample count uniform in [500, 4000], from the path's own splitmix64
+    stream (salted so that it is independent of the waypoint draws).
+    Returns (dofs [B] int32, samples [B] int32)."""
+    idx = np.arange(first_path_index, first_path_index + int(num_paths), dtype=np.uint64)
+    u = _splitmix_stream(idx + np.uint64(1 << 41), 2)
+    dofs = np.asarray(MIXED_DOFS, dtype=np.int32)[np.minimum((u[:, 0] * 3).astype(np.int64), 2)]
+    lo, hi = MIXED_SAMPLES
+    samples = (lo + np.floor(u[:, 1] * (hi - lo + 1))).astype(np.int32)
+    return dofs, np.minimum(samples, hi)
+
+
+def mixed_batch_groups(dofs, samples, bucket=MIXED_BUCKET):
+    """Bucket a mixed batch by (D, ceil(N / bucket)): one engine launch per bucket, with the
+    bucket's upper edge as the common sample stride. Returns {(D, stride): positions}."""
+    dofs, samples = np.asarray(dofs), np.asarray(samples)
+    groups = {}
+    for pos in range(len(dofs)):
+        key = (int(dofs[pos]), int(-(-int(samples[pos]) // bucket) * bucket))
+        groups.setdefault(key, []).append(pos)
+    return {k: np.asarray(v, dtype=np.int64) for k, v in sorted(groups.items())}
+
+
+def make_mixed_group(path_indices, num_dofs, samples, stride):
+    """The joint batch of one bucket: paths `path_indices` (global indices), each sampled at
+    its own count samples[i] <= stride over its whole length."""
+    b = make_joint_batch(len(path_indices), num_dofs, stride, path_indices=path_indices)
+    ns = np.asarray(samples, dtype=np.int32)
+    b["delta"] = np.ascontiguousarray(b["knots"][:, -1] / (ns - 1))
+    b["num_samples_per_path"] = ns
+    return b
 
 
 def eval_joint_splines(cps, knots, u):
