@@ -271,11 +271,14 @@ int tpamd_resample_skip_host(tpamd_engine *engine, const tpamd_resample_args *ar
 int tpamd_debug_copy_boundary(tpamd_engine *engine, int num_paths, int num_samples,
                               double *sd2_max, double *sdd_max, double *sdd_min,
                               double *sd2_zero, uint8_t *type, double *sd2);
+/* The specialised joint-space sweep kernels run CalculateBoundary's passes 2-4 themselves and
+ * keep sdd_max/sdd_min/type on chip; switch this on BEFORE a solve to have them stored for
+ * tpamd_debug_copy_boundary as well (off by default: 17 bytes per sample less HBM traffic). */
+void tpamd_debug_keep_boundary(tpamd_engine *engine, int on);
 
-/* Diagnostic builds (-DTPAMD_DIAG) only: per-path cycle counters of the sweep kernel,
- * [B][16] int64 (0 fwd extremals, 1 bwd extremals, 2 critical-point search, 3 tail,
- * 4 FindSdd steps, 5 whole loop, 8/9 boundary-following steps fwd/bwd, 10/11 FindSdd
- * steps fwd/bwd). The product build leaves them zero. */
+/* Diagnostic builds (-DTPAMD_DIAG) only: per-path counters of the specialised sweep kernel,
+ * [B][48] int64: slots 0..23 of the backward wave, 24..47 of the forward wave (meaning of a
+ * slot: csrc/tpamd_sweep_joint.h, JointSweep::diag). The product build leaves them zero. */
 int tpamd_debug_copy_diag(tpamd_engine *engine, int num_paths, long long *out);
 
 /* Per-kernel launch durations for bench.py: HIP events recorded on the launch stream

@@ -211,3 +211,47 @@ def test_engine_leaves_the_callers_device_current(env):
     E2.reserve(8, 100, 14)
     assert torch.cuda.current_device() == before
     E2.close()
+
+
+@pytest.mark.parametrize("kind,D,N,B", [("joint", 7, 700, 6), ("joint", 14, 300, 3), ("joint", 3, 130, 4),
+                                        ("cartesian", 6, 500, 4)])
+def test_fused_boundary_passes_match_the_oracle_stage_by_stage(env, kind, D, N, B):
+    """The specialised sweep kernels run CalculateBoundary's passes 2-4 for their path
+    (tpamd_sweep_joint.h boundary_passes_for_path). With tpamd_debug_keep_boundary the final
+    curve, its sdd range and the classification are stored: bit-equal to the oracle's
+    CalculateBoundary on the same rows."""
+    torch, eng, syn, tpo = (env[k] for k in ("torch", "eng", "syn", "tpo"))
+    E = eng.Engine(0)
+    E.debug_keep_boundary(True)
+    out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    if kind == "joint":
+        b = syn.make_joint_batch(B, D, N, first_path_index=400)
+        E.time_joint_paths(eng.upload_joint_batch(b, env["dev"]), out, N)
+    else:
+        b = syn.make_cartesian_batch(B, D, N, first_path_index=400)
+        E.time_cartesian_paths(syn.upload_cartesian_batch(b, env["dev"]), out)
+    torch.cuda.synchronize()
+    bd = E.debug_boundary(B, N)
+    for i in range(B):
+        if kind == "joint":
+            _, q1, q2 = tpo.joint_sample_path(b["knots"][i], b["control_points"][i], 0.0, b["delta"][i], N)
+            rows = tpo.joint_constraint_setup(q1, q2, b["vmax"][i], b["amax"][i])
+            C = 2 * D
+        else:
+            q1, q2 = tpo.cartesian_path_derivatives(b["ik_positions"][i], b["delta"][i])
+            # J q' summed over the joints in index order, as the oracle and the engine do
+            jq1 = np.stack([sum(b["jacobians"][i][:, r, d] * q1[:, d] for d in range(D))
+                            for r in range(6)], axis=1)
+            rows = tpo.cartesian_constraint_setup(q1, q2, np.ascontiguousarray(jq1), b["vmax"][i],
+                                                  b["amax"][i], b["vtrans"][i], b["vrot"][i])
+            C = 2 * D + 2
+        p = tpo.Profile(N, C)
+        p.set_max_loops(10 * N)
+        assert p.setup(*rows, 0.0, b["delta"][i] * (N - 1)) == 0
+        st = p.optimize()
+        assert st == out["status"][i].item()
+        np.testing.assert_array_equal(bd["sd2_max"][i], p.sd2_max)
+        np.testing.assert_array_equal(bd["sdd_max"][i], p.sdd_max_for_sd2_max)
+        np.testing.assert_array_equal(bd["sdd_min"][i], p.sdd_min_for_sd2_max)
+        np.testing.assert_array_equal(bd["type"][i], p.boundary_type)
+    E.close()

@@ -68,6 +68,7 @@ struct tpamd_engine {
   const double *last_time = nullptr;   // out->time of the last solve (tpamd_query_device's check)
   int profile = 0;             // 0 off, 1 every kernel, 2 the sweep kernel only
   bool force_generic = false;  // TPAMD_FORCE_GENERIC=1: A/B the specialised kernels
+  bool keep_boundary = false;  // tpamd_debug_keep_boundary
   // Event timing: pending (start, stop) pairs are folded into acc_ms/acc_n and their events
   // recycled through `pool` once kMaxPendingEvents are outstanding, so a long profiled run
   // holds a bounded number of HIP events.
@@ -115,7 +116,7 @@ size_t carve_workspace(char *base, int B, int N, int C, Workspace *ws) {
   w.Y = (double *)take(ns * 8);
   w.type = (uint8_t *)take(ns);
   w.sd2 = (double *)take(ns * 8);
-  w.diag = (long long *)take(nb * 16 * 8);
+  w.diag = (long long *)take(nb * 48 * 8);
   if (ws) *ws = w;
   return off;
 }
@@ -130,6 +131,7 @@ int ensure_workspace(tpamd_engine *e, int B, int N, int C) {
     e->ws_bytes = need;
   }
   carve_workspace((char *)e->ws_base, B, N, C, &e->ws);
+  e->ws.keep_boundary = e->keep_boundary ? 1 : 0;
   return 0;
 }
 
@@ -249,18 +251,15 @@ int configure_kernels_for_device(int device) {
   TPAMD_BIG_LDS(k_lp_rows<2>);
   TPAMD_BIG_LDS(k_sweep<JointSource>);
   TPAMD_BIG_LDS(k_sweep<GenericSource>);
-  TPAMD_BIG_LDS(k_sweep_joint<6, 1>);
-  TPAMD_BIG_LDS(k_sweep_joint<7, 1>);
-  TPAMD_BIG_LDS(k_sweep_joint<14, 1>);
-  TPAMD_BIG_LDS(k_sweep_joint<3, 2>);
-  TPAMD_BIG_LDS(k_sweep_joint<4, 2>);
-  TPAMD_BIG_LDS(k_sweep_joint<5, 2>);
+  TPAMD_BIG_LDS(k_sweep_joint<3>);
+  TPAMD_BIG_LDS(k_sweep_joint<4>);
+  TPAMD_BIG_LDS(k_sweep_joint<5>);
+  TPAMD_BIG_LDS(k_sweep_joint<6>);
+  TPAMD_BIG_LDS(k_sweep_joint<7>);
+  TPAMD_BIG_LDS(k_sweep_joint<8>);
+  TPAMD_BIG_LDS(k_sweep_joint<14>);
   TPAMD_BIG_LDS(k_sweep_joint<6, 2>);
   TPAMD_BIG_LDS(k_sweep_joint<7, 2>);
-  TPAMD_BIG_LDS(k_sweep_joint<8, 2>);
-  TPAMD_BIG_LDS(k_sweep_joint<14, 2>);
-  TPAMD_BIG_LDS(k_sweep_joint<6, 2, 2>);
-  TPAMD_BIG_LDS(k_sweep_joint<7, 2, 2>);
   TPAMD_BIG_LDS(k_cartesian_lp<1, 6>);
   TPAMD_BIG_LDS(k_cartesian_lp<1, 7>);
   TPAMD_BIG_LDS(k_resample_skip, 128 * 1024);   // int[N], N <= 32768, next to 8 B static
@@ -268,6 +267,10 @@ int configure_kernels_for_device(int device) {
   g_device_configured[device] = true;
   return 0;
 }
+
+// Joint counts with a specialised sweep kernel (which also runs the boundary passes 2-4 of
+// its path and the planner epilogue).
+bool has_joint_sweep(int D) { return (D >= 3 && D <= 8) || D == 14; }
 
 // The sweep launch: joint-space batches with D in {3..8, 14} take the specialised kernel
 // (6, 7, 14 are the BASELINE.json configurations), everything else the generic one.
@@ -286,48 +289,41 @@ template <>
 bool launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
                                const Workspace &ws, const tpamd_path_outputs *out,
                                bool force_generic) {
-  const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
-  // two waves per path (backward / forward extremals of a switching point run
-  // concurrently) unless TPAMD_SWEEP_WAVES=1
-  static const int waves = [] {
-    const char *v = std::getenv("TPAMD_SWEEP_WAVES");
-    return (v && v[0] == '1') ? 1 : 2;
-  }();
 #define TPAMD_LAUNCH_JOINT(DD)                                                                   \
   do {                                                                                           \
-    if (waves == 2)                                                                              \
-      hipLaunchKernelGGL((k_sweep_joint<DD, 2>), dim3(B), dim3(128),                             \
-                         sweep_joint_lds_bytes<DD>(N, 2), st, N, max_loops, src, ws, out->time,  \
-                         out->s, out->sd, out->sdd, out->last_extremal_index,                    \
-                         out->max_time_increment, out->status, out->qd, out->qdd);               \
-    else                                                                                         \
-      hipLaunchKernelGGL((k_sweep_joint<DD, 1>), dim3(B), dim3(64),                              \
-                         sweep_joint_lds_bytes<DD>(N, 1), st, N, max_loops, src, ws, out->time,  \
-                         out->s, out->sd, out->sdd, out->last_extremal_index,                    \
-                         out->max_time_increment, out->status, out->qd, out->qdd);               \
+    hipLaunchKernelGGL((k_sweep_joint<DD>), dim3(B), dim3(128), sweep_joint_lds_bytes<DD>(N), st, \
+                       N, max_loops, src, ws, out->time, out->s, out->sd, out->sdd,              \
+                       out->last_extremal_index, out->max_time_increment, out->status, out->qd,  \
+                       out->qdd);                                                                \
+    return true;                                                                                 \
   } while (0)
-  if (!force_generic && src.D == 7) { TPAMD_LAUNCH_JOINT(7); return true; }
-  if (!force_generic && src.D == 6) { TPAMD_LAUNCH_JOINT(6); return true; }
-  if (!force_generic && src.D == 14) { TPAMD_LAUNCH_JOINT(14); return true; }
+  if (!force_generic) {
+    switch (src.D) {
+      case 3: TPAMD_LAUNCH_JOINT(3);
+      case 4: TPAMD_LAUNCH_JOINT(4);
+      case 5: TPAMD_LAUNCH_JOINT(5);
+      case 6: TPAMD_LAUNCH_JOINT(6);
+      case 7: TPAMD_LAUNCH_JOINT(7);
+      case 8: TPAMD_LAUNCH_JOINT(8);
+      case 14: TPAMD_LAUNCH_JOINT(14);
+      default: break;
+    }
+  }
 #undef TPAMD_LAUNCH_JOINT
-  // further joint counts: the two-wave kernel only
-#define TPAMD_LAUNCH_JOINT2(DD)                                                                  \
-  hipLaunchKernelGGL((k_sweep_joint<DD, 2>), dim3(B), dim3(128), sweep_joint_lds_bytes<DD>(N, 2), \
-                     st, N, max_loops, src, ws, out->time, out->s, out->sd, out->sdd,            \
-                     out->last_extremal_index, out->max_time_increment, out->status, out->qd,    \
-                     out->qdd)
-  if (!force_generic && src.D == 3) { TPAMD_LAUNCH_JOINT2(3); return true; }
-  if (!force_generic && src.D == 4) { TPAMD_LAUNCH_JOINT2(4); return true; }
-  if (!force_generic && src.D == 5) { TPAMD_LAUNCH_JOINT2(5); return true; }
-  if (!force_generic && src.D == 8) { TPAMD_LAUNCH_JOINT2(8); return true; }
-#undef TPAMD_LAUNCH_JOINT2
+  const size_t lds = (2 * (size_t)N + 64) * sizeof(double);
   hipLaunchKernelGGL((k_sweep<JointSource>), dim3(B), dim3(64), lds, st, N, max_loops, src, ws,
                      out->time, out->s, out->sd, out->sdd, out->last_extremal_index,
                      out->max_time_increment, out->status);
   return false;
 }
 
-// Shared tail: detect -> final -> sweep (-> epilogue in joint mode).
+template <class Source> bool sweep_runs_boundary_passes(const tpamd_engine *, const Source &) { return false; }
+template <> bool sweep_runs_boundary_passes<JointSource>(const tpamd_engine *e, const JointSource &src) {
+  return !e->force_generic && has_joint_sweep(src.D);
+}
+
+// Shared tail: boundary passes 2-4 (separate kernels unless the sweep kernel runs them itself)
+// -> sweep (-> epilogue in joint mode).
 template <class Source>
 int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int max_loops,
                            const Source &src, const tpamd_path_outputs *out,
@@ -335,14 +331,16 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
   e->ws.sd2_out = out->sd2;
   const Workspace &ws = e->ws;
   const dim3 grid_s((N + 255) / 256, B);
-  {
-    Timer t(e, st, KI_DETECT);
-    hipLaunchKernelGGL((k_boundary_zfit<Source>), grid_s, dim3(256), 0, st, N, src, ws);
-    hipLaunchKernelGGL(k_boundary_detect, grid_s, dim3(256), 0, st, N, ws);
-  }
-  {
-    Timer t(e, st, KI_FINAL);
-    hipLaunchKernelGGL((k_boundary_final<Source>), grid_s, dim3(256), 0, st, N, src, ws);
+  if (!sweep_runs_boundary_passes(e, src)) {
+    {
+      Timer t(e, st, KI_DETECT);
+      hipLaunchKernelGGL((k_boundary_zfit<Source>), grid_s, dim3(256), 0, st, N, src, ws);
+      hipLaunchKernelGGL(k_boundary_detect, grid_s, dim3(256), 0, st, N, ws);
+    }
+    {
+      Timer t(e, st, KI_FINAL);
+      hipLaunchKernelGGL((k_boundary_final<Source>), grid_s, dim3(256), 0, st, N, src, ws);
+    }
   }
   {
     Timer t(e, st, KI_SWEEP);
@@ -357,8 +355,8 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
 template <int DD>
 void launch_sweep_cartesian(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
                             const Workspace &ws, const tpamd_path_outputs *out) {
-  hipLaunchKernelGGL((k_sweep_joint<DD, 2, 2>), dim3(B), dim3(128),
-                     (sweep_joint_lds_bytes<DD, 2>(N, 2)), st, N, max_loops, src, ws, out->time,
+  hipLaunchKernelGGL((k_sweep_joint<DD, 2>), dim3(B), dim3(128),
+                     (sweep_joint_lds_bytes<DD, 2>(N)), st, N, max_loops, src, ws, out->time,
                      out->s, out->sd, out->sdd, out->last_extremal_index,
                      out->max_time_increment, out->status, out->qd, out->qdd);
 }
@@ -591,16 +589,6 @@ int tpamd_time_cartesian_paths_device(tpamd_engine *e, const tpamd_cartesian_bat
     JointSource src;
     src.q12 = ws.q12; src.lim = ws.lim; src.D = D; src.E = 2;
     e->ws.sd2_out = out->sd2;
-    const dim3 grid_s((N + 255) / 256, B);
-    {
-      Timer t(e, st, KI_DETECT);
-      hipLaunchKernelGGL((k_boundary_zfit<JointSource>), grid_s, dim3(256), 0, st, N, src, e->ws);
-      hipLaunchKernelGGL(k_boundary_detect, grid_s, dim3(256), 0, st, N, e->ws);
-    }
-    {
-      Timer t(e, st, KI_FINAL);
-      hipLaunchKernelGGL((k_boundary_final<JointSource>), grid_s, dim3(256), 0, st, N, src, e->ws);
-    }
     {
       Timer t(e, st, KI_SWEEP);
       if (D == 6) launch_sweep_cartesian<6>(st, B, N, max_loops, src, e->ws, out);
@@ -1050,11 +1038,15 @@ int tpamd_debug_copy_boundary(tpamd_engine *e, int B, int N, double *sd2_max, do
   return 0;
 }
 
+void tpamd_debug_keep_boundary(tpamd_engine *e, int on) {
+  if (e) e->keep_boundary = on != 0;
+}
+
 int tpamd_debug_copy_diag(tpamd_engine *e, int B, long long *out) {
   if (!e || !out || B != e->last_B) return TPAMD_E_INVALID_ARGUMENT;
   TPAMD_ON_DEVICE(e);
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, e->ws.diag, (size_t)B * 16 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, e->ws.diag, (size_t)B * 48 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -29,9 +29,10 @@ struct Workspace {
   double *lim;  // [B][2][C] lower then upper (joint mode)
   // per (path, sample)
   // joint mode: one record of R = 2D+2 doubles per sample,
-  //   [q'_0, q''_0, ..., q'_{D-1}, q''_{D-1}, sd2_max (final), type bits]
-  // so that the sweep streams exactly one contiguous record per step. The first 2D
-  // entries are written by k_sample_lp_joint, the last two by k_boundary_final.
+  //   [q'_0, q''_0, ..., q'_{D-1}, q''_{D-1}, (pad, pad)]
+  // so that the sweep streams one contiguous, 16-byte aligned record per step. The first 2D
+  // entries are written by k_sample_lp_joint; in the LDS copy of a record the pad holds the
+  // final sd2_max and the type bits (JointSweep::store_tile).
   double *q12;
   double *m0, *z0, *X0, *Y0, *Xz, *Yz;  // pass-1 boundary, [B][N]
   uint8_t *at0;                          // sd2_max_at_sdd0
@@ -42,6 +43,7 @@ struct Workspace {
   double *sd2;
   long long *diag;  // [B][16] cycle counters; filled only by -DTPAMD_DIAG builds
   double *sd2_out;  // optional caller copy of sd2 ([B][N]); may be null
+  int keep_boundary;  // the fused boundary passes also store sdd_max/sdd_min/type (debug copy)
 };
 
 __device__ __forceinline__ int path_samples(const Workspace &ws, int b, int N) {
@@ -57,12 +59,6 @@ struct JointSource {
   __device__ __forceinline__ int b_only_from() const { return D; }   // rows D.. have A = 0
   static constexpr bool kJoint = true;
   __device__ __forceinline__ int stride() const { return 2 * D + E + 2; }
-  // final boundary value and classification into the sample's record
-  __device__ __forceinline__ void put_record(int b, int N, int idx, double m, uint8_t type) const {
-    double *rec = const_cast<double *>(q12) + ((size_t)b * N + idx) * stride() + 2 * D + E;
-    rec[0] = m;
-    rec[1] = __longlong_as_double((long long)type);
-  }
   __device__ __forceinline__ JointRowsAt at(int b, int N, int idx) const {
     JointRowsAt r;
     r.q12 = q12 + ((size_t)b * N + idx) * stride();
@@ -80,7 +76,6 @@ struct GenericSource {
   __device__ __forceinline__ int rows() const { return C; }
   __device__ __forceinline__ int b_only_from() const { return -1; }
   static constexpr bool kJoint = false;
-  __device__ __forceinline__ void put_record(int, int, int, double, uint8_t) const {}
   __device__ __forceinline__ GlobalRowsAt at(int b, int N, int idx) const {
     const size_t o = ((size_t)b * N + idx) * C;
     GlobalRowsAt r;
@@ -656,14 +651,28 @@ __device__ __forceinline__ void wave_find_sdd_both(const R &r, int C, double sd2
 // Same for small constraint sets, four samples per wave: each 16-lane group owns one sample
 // (rows in lanes 0..C-1 of the group, C <= 16, and its <= 16 candidates one per lane); rows are
 // broadcast inside the group with shuffles. `valid` is false for a group without a sample.
+// Row registers of group16_find_sdd_both: lane gl of a 16-lane group holds row gl of the
+// group's sample (zeros beyond C / for a group without a sample).
+struct Group16Rows {
+  double a, b, lo, hi;
+};
 template <class R>
-__device__ __forceinline__ void group16_find_sdd_both(const R &r, bool valid, int C, double sd2,
-                                                      int lane, double *sdd_max, double *sdd_min,
-                                                      int b_only_from) {
+__device__ __forceinline__ Group16Rows group16_load_rows(const R &r, bool valid, int C, int lane) {
+  const int gl = lane & 15;
+  const bool has = valid && gl < C;
+  Group16Rows g;
+  g.a = has ? r.a(gl) : 0.0;
+  g.b = has ? r.b(gl) : 0.0;
+  g.lo = has ? r.lo(gl) : 0.0;
+  g.hi = has ? r.hi(gl) : 0.0;
+  return g;
+}
+__device__ __forceinline__ void group16_find_sdd_both_rows(const Group16Rows &g, bool valid, int C,
+                                                           double sd2, int lane, double *sdd_max,
+                                                           double *sdd_min, int b_only_from) {
   const int gl = lane & 15, gb = lane & 48;
   const bool has = valid && gl < C;
-  const double a_m = has ? r.a(gl) : 0.0, b_m = has ? r.b(gl) : 0.0;
-  const double lo_m = has ? r.lo(gl) : 0.0, hi_m = has ? r.hi(gl) : 0.0;
+  const double a_m = g.a, b_m = g.b, lo_m = g.lo, hi_m = g.hi;
   const int Cc = (b_only_from >= 0) ? b_only_from : C;
   bool fixed_bad = false;
   if (b_only_from >= 0 && has && gl >= b_only_from) {
@@ -698,6 +707,13 @@ __device__ __forceinline__ void group16_find_sdd_both(const R &r, bool valid, in
   if (smin == DBL_MAX) smin = 0;
   *sdd_max = smax;
   *sdd_min = smin;
+}
+template <class R>
+__device__ __forceinline__ void group16_find_sdd_both(const R &r, bool valid, int C, double sd2,
+                                                      int lane, double *sdd_max, double *sdd_min,
+                                                      int b_only_from) {
+  const Group16Rows g = group16_load_rows(r, valid, C, lane);
+  group16_find_sdd_both_rows(g, valid, C, sd2, lane, sdd_max, sdd_min, b_only_from);
 }
 
 // Whether group16_find_sdd_both applies to a source.
@@ -843,7 +859,6 @@ __global__ void __launch_bounds__(256) k_boundary_final(int stride, Source src, 
   // NextCriticalPoint makes against sd2_max_for_sdd0[0] (.cc:710) for the sweep kernel.
   if (m == ws.z0[pb]) type |= kBndEqualsZ00;
   ws.type[pb + j] = type;
-  src.put_record(b, stride, j, m, type);
 }
 
 // ------------------------------------------------------------- K2: the sweep

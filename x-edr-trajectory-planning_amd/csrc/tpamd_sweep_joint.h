@@ -167,7 +167,18 @@ struct JointSweep {
   static constexpr int kChunks = kTileSamples * R / 2;      // 16-byte chunks per tile
   static constexpr int kChunksPerLane = (kChunks + 63) / 64;
 #ifdef TPAMD_DIAG
-  long long diag[16];
+  // per wave: 0 extremal cycles inside the loop, 1 cycles waiting for the partner at the end of
+  // a loop, 2 critical-point search, 3 tail, 4 chain-block cycles, 5 first pair + loop, 6 chain
+  // blocks, 7 critical-point mismatches (must be 0), 8 boundary-following blocks, 9 first pair,
+  // 10 scalar FindSdd steps, 11 loops, 12 qd/qdd written inside the loop (backward wave), 13
+  // tail up to the start of the time samples, 14 chain steps accepted, 15 whole kernel after
+  // set-up, 16 tail: sd/dt pass, 17 tail: time integral (backward wave) / last-extremal scan +
+  // remaining qd/qdd (forward wave), 18 the literal critical-point walk of this build (to be
+  // subtracted from 5 and 15), 19..22 boundary passes (cumulative: flags loaded, re-fits next to
+  // isolated points, deferred fixes, final values + classification), 23 re-fits of the final
+  // pass. During the boundary passes 10 / 11 count the re-fits of the final / the first pass
+  // (the sweep then counts on top: scalar FindSdd steps / loops).
+  long long diag[24];
 #endif
   int N, lane;
   double ds, two_ds;
@@ -178,6 +189,13 @@ struct JointSweep {
   const double *m_g;      // global: final sd2_max of this path [N]
   const double *rec;      // global: records of this path [N][R]
   int tag0, tag1;         // tile index resident in ring slot 0 / 1 (-1: none)
+  // Planner epilogue (see emit_range): output rows of this path [N][D] (null: not requested),
+  // the clamp limits a_max[D] in LDS, and the LDS bitmap of samples whose qd/qdd are redone
+  // after the tail changed their sdd.
+  double *qd_g, *qdd_g;
+  const double *aml;
+  uint32_t *dirty;
+  int end_idx;            // sample at which the last extremal of this wave ended
   // per-lane constants (roles are folded into data so that the hot loop has no role
   // branches): idle lanes carry lim = NaN (their candidate is NaN, hence rejected) and
   // vel_hi = +inf (their velocity check never fails).
@@ -217,24 +235,38 @@ struct JointSweep {
   // The prefetch registers live in the calling extremal (a struct-member array is not
   // promoted to registers). Loads always cover a full tile: a partial last tile reads at
   // most 31 records past the path's end, still inside the engine workspace (never used).
+  // The (sd2_max, type) pair at the end of a record is NOT read from global memory: the final
+  // boundary value comes from the dense array ws.m (one coalesced load by lanes 0..31) and the
+  // classification from the LDS type copy, and both are dropped into the tile's records as it
+  // is stored (the boundary passes would otherwise have to patch 16 bytes into every 128-byte
+  // record: one write transaction per sample).
   struct Prefetch {
     RegPack<kChunksPerLane> r;
+    double m;  // lanes 0..kTileSamples-1: final sd2_max of sample t*kTileSamples + lane
     int tag;   // tile index held in r (-1: none)
   };
   __device__ __forceinline__ void issue_tile_loads(int t, Prefetch &pf) const {
     const f64x2 *src = reinterpret_cast<const f64x2 *>(rec + (size_t)t * kTileSamples * R);
     pf.r.template load<kChunks>(src, lane);
+    pf.m = m_g[min(t * kTileSamples + (lane & (kTileSamples - 1)), N - 1)];
     pf.tag = t;
   }
   __device__ __forceinline__ void store_tile(int slot, const Prefetch &pf) const {
     f64x2 *dst = reinterpret_cast<f64x2 *>(tiles + (size_t)slot * kTileSamples * R);
     pf.r.template store<kChunks>(dst, lane);
+    wave_lds_sync();                 // the chunk stores land before the (m, type) pairs
+    if (lane < kTileSamples) {
+      const int i = min(pf.tag * kTileSamples + lane, N - 1);
+      f64x2 mt;
+      mt.x = pf.m;
+      mt.y = __longlong_as_double((long long)typel[i]);
+      dst[(size_t)lane * (R / 2) + kMt] = mt;
+    }
     wave_lds_sync();
   }
   // Make tile t resident; dir tells which neighbour tile to prefetch afterwards.
   __device__ __forceinline__ void fill_tile(int t, int dir, Prefetch &pf) {
-    TPAMD_CNT(12);
-    if (pf.tag != t) { TPAMD_CNT(13); issue_tile_loads(t, pf); }
+    if (pf.tag != t) issue_tile_loads(t, pf);
     wave_lds_sync();                 // earlier readers of this slot are done
     store_tile(t & 1, pf);           // waits for the loads, writes LDS
     if (t & 1) tag1 = t; else tag0 = t;
@@ -270,6 +302,72 @@ struct JointSweep {
   }
   __device__ __forceinline__ void put_sdd(int i, double v) {
     if (lane == 0) sdd_g[i] = v;
+  }
+
+  // ---- planner epilogue, incrementally (path_timing_trajectory.cc:458-472) ---------------
+  // qd = q' sd, qdd = clamp(q' sdd + q'' sd^2, +-a_max) with sd = sqrt(sd2). The backward wave
+  // finishes its extremal of a switching point well before the forward wave does; instead of
+  // idling at the loop's closing barrier it writes qd/qdd for the samples below the current
+  // critical point, which no extremal of this loop touches any more (emit_range, called from
+  // the kernel). A later backward extremal that reaches below that frontier makes the kernel
+  // redo the overlap; whatever is left after the last loop, and the few samples whose sdd the
+  // tail changes (mark_dirty), are written in the tail. The records are read a second time here
+  // (mostly from L2: the forward wave streamed them shortly before), but spread over the whole
+  // kernel instead of as one bandwidth-bound pass by every path at once.
+  __device__ __forceinline__ bool emitting() const { return qd_g != nullptr || qdd_g != nullptr; }
+  __device__ __forceinline__ void emit_value(int i, int d, f64x2 pr, double v, double a,
+                                             double amx) const {
+    const size_t o = (size_t)i * D + d;
+    if (qd_g) qd_g[o] = pr.x * v;
+    if (qdd_g) {
+      const double v2 = v * v;
+      double acc = pr.x * a + pr.y * v2;
+      if (acc < -amx) acc = -amx;
+      if (acc > amx) acc = amx;
+      qdd_g[o] = acc;
+    }
+  }
+  // Samples lo..hi (inclusive) from the current sd2 (LDS), sdd and records (global); one thread
+  // per (sample, joint), consecutive threads store consecutive addresses; four passes in
+  // flight. `t` of `nthreads` threads take part (one wave: lane of 64; the workgroup: tid of 128).
+  // stop != nullptr: give up as soon as *stop == stop_value (checked between batches) -- the
+  // partner wave has finished and must not be kept waiting. Returns the first sample NOT
+  // written (hi + 1 if the range was completed).
+  __device__ __forceinline__ int emit_range(int lo, int hi, int t, int nthreads,
+                                            const volatile int *stop = nullptr,
+                                            int stop_value = 0) const {
+    if (!emitting() || hi < lo) return hi + 1;
+    const f64x2 *rec2 = reinterpret_cast<const f64x2 *>(rec);
+    const int total = (hi - lo + 1) * D;
+#ifndef TPAMD_EMIT_UNROLL
+#define TPAMD_EMIT_UNROLL 8
+#endif
+    constexpr int U = TPAMD_EMIT_UNROLL;
+    for (int b0 = 0; b0 < total; b0 += nthreads * U) {
+      if (stop != nullptr && *stop == stop_value) return lo + b0 / D;   // (uniform)
+      const int e0 = b0 + t;
+      f64x2 pr[U];
+      double s2[U], a[U], amx[U];
+      int ii[U], dd[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int e = min(e0 + nthreads * u, total - 1);
+        const int se = e / D;
+        ii[u] = lo + se;
+        dd[u] = e - se * D;
+        pr[u] = rec2[(size_t)ii[u] * (R / 2) + dd[u]];
+        s2[u] = sd2[ii[u]];
+        a[u] = sdd_g[ii[u]];
+        amx[u] = aml[dd[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+        if (e0 + nthreads * u < total) emit_value(ii[u], dd[u], pr[u], sqrt(s2[u]), a[u], amx[u]);
+    }
+    return hi + 1;
+  }
+  __device__ __forceinline__ void mark_dirty(int i) const {
+    if (lane == 0) atomicOr(&dirty[i >> 5], 1u << (i & 31));
   }
 
   // FindSddMax (MAX) / FindSddMin, time_optimal_path_timing.cc:638-695.
@@ -396,6 +494,7 @@ struct JointSweep {
       if (derivs_valid(index, c, s2)) { res = c; done = true; }
     }
     put_sdd(index, res);
+    end_idx = index;
   }
 
   // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952)
@@ -443,12 +542,11 @@ struct JointSweep {
     const bool on_boundary = is_tiny(cur - m_i);
     double sd2tmp, sddtmp;
     if (on_boundary && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {
-      TPAMD_CNT(FWD ? 8 : 9);
       sd2tmp = m_n;
       sddtmp = FWD ? 0.5 * (sd2tmp - cur) / ds : 0.5 * (cur - sd2tmp) / ds;
       c.win = -1;
     } else {
-      TPAMD_CNT(FWD ? 10 : 11);
+      TPAMD_CNT(10);
       int win;
       sddtmp = uniform_f64(find_sdd<FWD>(use, cur, win));
       c.win = uniform_i32(win);
@@ -466,6 +564,7 @@ struct JointSweep {
       const bool stop = FWD ? (type_invalid || deriv_invalid)
                             : ((type_invalid || deriv_invalid) && !(idx_start != (N - 1)));
       if (stop) {
+        end_idx = idx;
         TPAMD_PAIR_SIGNAL();
         return idx;
       }
@@ -484,6 +583,7 @@ struct JointSweep {
     }
     put_sd2(nidx, sd2tmp);
     put_sdd(idx, sddtmp);
+    if (!more) end_idx = nidx;
     TPAMD_PAIR_SIGNAL();
     if (!more) return FWD ? N - 1 : 0;
     c.idx = nidx;
@@ -531,9 +631,9 @@ struct JointSweep {
     const unsigned long long mask = __ballot(elig);
     const int L = (~mask == 0ull) ? 64 : (__ffsll((long long)~mask) - 1);
     if (L == 0) return 0;
+    const double cur_k = (lane == 0) ? c.cur : m_j;
+    const double sddv = FWD ? 0.5 * (m_jn - cur_k) / ds : 0.5 * (cur_k - m_jn) / ds;
     if (lane < L) {
-      const double cur_k = (lane == 0) ? c.cur : m_j;
-      const double sddv = FWD ? 0.5 * (m_jn - cur_k) / ds : 0.5 * (cur_k - m_jn) / ds;
       sd2[j + dir] = m_jn;
       sdd_g[j] = sddv;
     }
@@ -671,6 +771,7 @@ struct JointSweep {
     }                                                         \
   } while (0)
     if (FWD ? !(idx_start < N - 2) : !(idx_start > 1)) {
+      end_idx = idx_start;
       TPAMD_PAIR_SIGNAL();
       if (wait_pair) __syncthreads();
       return FWD ? N - 1 : 0;
@@ -686,9 +787,12 @@ struct JointSweep {
   if (is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {      \
     const int run = uniform_i32(follow_boundary<FWD>(c));                                    \
     if (run > 0) {                                                                           \
-      TPAMD_CNT(FWD ? 8 : 9);                                                                \
+      TPAMD_CNT(8);                                                                          \
       TPAMD_PAIR_SIGNAL();                                                                   \
-      if (FWD ? !(c.idx < N - 2) : !(c.idx > 1)) return FWD ? N - 1 : 0;                     \
+      if (FWD ? !(c.idx < N - 2) : !(c.idx > 1)) {                                           \
+        end_idx = c.idx;                                                                     \
+        return FWD ? N - 1 : 0;                                                              \
+      }                                                                                      \
       init_carry<FWD>(c.idx, c, rows_a, pf, false);                                          \
       continue;                                                                              \
     }                                                                                        \
@@ -707,8 +811,11 @@ struct JointSweep {
     trust = total > 0;                                                                       \
     last_win = -1;                                                                           \
     if (total > 0) {                                                                         \
-      TPAMD_ADD(FWD ? 14 : 15, total);                                                       \
-      if (FWD ? !(c.idx < N - 2) : !(c.idx > 1)) return FWD ? N - 1 : 0;                     \
+      TPAMD_ADD(14, total);                                                                  \
+      if (FWD ? !(c.idx < N - 2) : !(c.idx > 1)) {                                           \
+        end_idx = c.idx;                                                                     \
+        return FWD ? N - 1 : 0;                                                              \
+      }                                                                                      \
       init_carry<FWD>(c.idx, c, rows_a, pf, false);                                          \
       continue;                                                                              \
     }                                                                                        \
@@ -800,27 +907,327 @@ struct JointSweep {
 #endif
 };
 
-// Dynamic LDS (bytes): sd2[N]*8 | tile rings WAVES*2*32*R*8 | type copy N (padded to 16) |
-// exchange words 16 B
-template <int D, int E = 0>
-__host__ __device__ inline size_t sweep_joint_lds_bytes(int N, int waves) {
-  return (size_t)N * 8 + (size_t)waves * 2 * kTileSamples * (2 * D + E + 2) * 8 +
-         (((size_t)N + 15) / 16) * 16 + 16;
+// ---------------------------------------------------------------------------------------
+// CalculateBoundary passes 2-4 (time_optimal_path_timing.cc:1381-1484) for ONE path, run by
+// the 128 threads of the path's sweep workgroup before the sweep starts. Same arithmetic as
+// k_boundary_zfit / k_boundary_detect / k_boundary_final (tpamd_kernels.h, which stay in use
+// for the generic kernels; the derivations of what the reference's in-place passes amount to
+// per sample are in the comments there) -- but per path instead of per 256 samples of the
+// whole batch: the pass-2/3 flags live in LDS, only the sparse re-fit values travel through
+// global memory, and three launches with their round trips through HBM disappear.
+// Every thread handles four samples per trip with all their loads issued up front (the
+// values a sample does not need are loaded and dropped: valid addresses, no dependence on
+// them); the sparse FindSddMax/Min re-fits are collected per wave and run four at a time with
+// the rows of the next four already in flight.
+//   at_l, ff_l: LDS bytes [N] (sd2_max_at_sdd0 flags of pass 1; deferred-fix flags of pass 2)
+//   scratch:    LDS, kRefitLdsBytes per wave (re-fit lists)
+//   typel:      LDS bytes [N], receives the final classification (incl. the kBndEqualsZ00 bit)
+// keep: also store sdd_max/sdd_min/type to the workspace (tpamd_debug_copy_boundary).
+// ---------------------------------------------------------------------------------------
+constexpr int kRefitCap = 128;                                  // list entries per wave
+constexpr int kRefitLdsBytes = kRefitCap * (4 + 8 + 8);          // idx | value | m_next
+
+template <int D, int E>
+struct PathBoundary {
+  const JointSource &src;
+  const Workspace &ws;
+  int b, N, stride, lane;
+  size_t pb;
+  double ds, z00;
+  const uint8_t *at_l;
+  uint8_t *ff_l, *typel;
+  bool keep;
+  // the wave's re-fit list
+  int *l_idx;
+  double *l_val, *l_nxt;
+  int count;
+
+  __device__ __forceinline__ void append(bool need, int j, double val, double nxt) {
+    const unsigned long long mask = __ballot(need);
+    if (!mask) return;
+    if (need) {
+      const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+      l_idx[pos] = j;
+      l_val[pos] = val;
+      l_nxt[pos] = nxt;
+    }
+    count += __popcll(mask);
+  }
+
+  // FindSddMax / FindSddMin (.cc:638-695) of sample j at sd2 by one thread
+  __device__ __forceinline__ void refit_one(int j, double sd2v, double *x, double *y) const {
+    constexpr int R = 2 * D + E + 2;
+    const f64x2 *rec2 = reinterpret_cast<const f64x2 *>(src.q12 + ((size_t)b * stride + j) * R);
+    const double *lim_lo = src.lim + (size_t)b * 2 * (2 * D + E), *lim_hi = lim_lo + 2 * D + E;
+    double a[D], bq[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const f64x2 p = rec2[d];
+      a[d] = p.x;
+      bq[d] = p.y;
+    }
+    bool ok = true;
+    if (E > 0) {
+      const f64x2 ex = rec2[D];
+      const double vt = ex.x * sd2v, vr = ex.y * sd2v;
+      ok = !(vt + kTiny < lim_lo[2 * D] || vt - kTiny > lim_hi[2 * D]) &&
+           !(vr + kTiny < lim_lo[2 * D + 1] || vr - kTiny > lim_hi[2 * D + 1]);
+    }
+    if (ok) find_sdd_both_joint_fixed<D>(a, bq, lim_hi, sd2v, x, y);
+  }
+
+  // pass 4 for one sample whose final boundary value and sdd range are known (.cc:1459-1484)
+  __device__ __forceinline__ void finalize(int j, double m, double X, double Y, double m_next) const {
+    uint8_t type = kBndNone;
+    if (j >= 1 && j <= N - 2) {
+      const double sd2p = (m_next - m) / ds;
+      const double sd2p_min = 2 * Y;
+      const double sd2p_max = 2 * X;
+      if (sd2p < sd2p_min) type = kBndSink;
+      else if (sd2p > sd2p_max) type = kBndSource;
+      if ((sd2p <= sd2p_max) && (sd2p >= sd2p_min)) type = kBndTrajectory;
+    }
+    if (m == z00) type |= kBndEqualsZ00;   // cached comparison of NextCriticalPoint (.cc:710)
+    ws.m[pb + j] = m;
+    typel[j] = type;
+    if (keep) {
+      ws.X[pb + j] = X;
+      ws.Y[pb + j] = Y;
+      ws.type[pb + j] = type;
+    }
+  }
+
+  // FindSddMax/Min (.cc:638-695) for every listed sample at its listed sd2. FINAL = false: the
+  // results are sd2_max_for_sdd0's sdd range next to isolated points (Xz, Yz); FINAL = true: they
+  // complete the sample (finalize).
+  template <bool FINAL>
+  __device__ __forceinline__ void flush(long long *diag) {
+    TPAMD_T0(tf);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int n = count;
+    // one listed sample per lane, all at once: the sample's (q', q'') pairs go to registers and
+    // FindSddMax/Min run as in K1 (find_sdd_both_joint_fixed; the Cartesian extra rows have A = 0
+    // and only gate the result, as in k_cartesian_lp)
+    for (int e = lane; e < n; e += 64) {
+      const int j = l_idx[e];
+      const double val = l_val[e];
+      double x = 0.0, y = 0.0;
+      refit_one(j, val, &x, &y);
+      if (FINAL) finalize(j, val, x, y, l_nxt[e]);
+      else { ws.Xz[pb + j] = x; ws.Yz[pb + j] = y; }
+    }
+    count = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (FINAL) TPAMD_ACC(23, tf);
+  }
+};
+
+template <int D, int E>
+__device__ __forceinline__ void boundary_passes_for_path(const JointSource &src, const Workspace &ws, int b,
+                                                         int N, int stride, int tid, uint8_t *at_l,
+                                                         uint8_t *ff_l, char *scratch, uint8_t *typel,
+                                                         bool keep, long long *diag) {
+  TPAMD_T0(tp0);
+  const size_t pb = (size_t)b * stride;
+  const int lane = tid & 63, w = tid >> 6;
+  const double *m0 = ws.m0 + pb, *z0 = ws.z0 + pb, *X0 = ws.X0 + pb, *Y0 = ws.Y0 + pb;
+  const double *Xz = ws.Xz + pb, *Yz = ws.Yz + pb, *fv = ws.fix_val + pb;
+  PathBoundary<D, E> P{src, ws, b, N, stride, lane, pb, ws.ds[b], z0[0], at_l, ff_l, typel, keep,
+                         nullptr, nullptr, nullptr, 0};
+  {
+    char *mine = scratch + (size_t)w * kRefitLdsBytes;
+    P.l_val = reinterpret_cast<double *>(mine);
+    P.l_nxt = P.l_val + kRefitCap;
+    P.l_idx = reinterpret_cast<int *>(P.l_nxt + kRefitCap);
+  }
+  const double ds = P.ds;
+  constexpr int U = 4;
+  const int hi_i = N - 1;
+  auto cl = [hi_i](int i) { return min(max(i, 0), hi_i); };     // clamp an index into the path
+
+  for (int i = tid; i < N; i += 128) at_l[i] = ws.at0[pb + i];
+  __syncthreads();
+  TPAMD_ACC(19, tp0);
+
+  // pass 2, first half (.cc:1386-1395): FindSddMax/Min at sd2_max_for_sdd0 next to isolated points
+  for (int base = 64 * w; base < N; base += 128) {
+    const int j = base + lane;
+    const bool need = j < N && (iso_at(at_l, N, j - 1) || iso_at(at_l, N, j + 1));
+    if (P.count + 64 > kRefitCap) P.template flush<false>(diag);
+    P.append(need, j, need ? z0[j] : 0.0, 0.0);
+  }
+  P.template flush<false>(diag);
+  __threadfence_block();
+  __syncthreads();
+  TPAMD_ACC(20, tp0);
+
+  // pass 2, second half (.cc:1396-1431): skipped maxima -> deferred fixes
+  for (int k0 = tid; k0 < N; k0 += 128 * U) {
+    double m0l[U], m0c[U], m0r[U], z0l[U], z0c[U], z0r[U], X0l[U], X0c[U], Y0c[U], Y0r[U];
+    double Xzl[U], Xzc[U], Xzr[U], Yzr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = k0 + 128 * u;
+      const int kl = cl(k - 1), kc = cl(k), kr = cl(k + 1);
+      m0l[u] = m0[kl]; m0c[u] = m0[kc]; m0r[u] = m0[kr];
+      X0l[u] = X0[kl]; X0c[u] = X0[kc];
+      Y0c[u] = Y0[kc]; Y0r[u] = Y0[kr];
+      // sd2_max_for_sdd0 and the values re-fitted there matter only next to isolated points
+      // (about 3 % of the samples): loaded where needed instead of streaming the arrays
+      const bool ik = iso_at(at_l, N, k), ik1 = iso_at(at_l, N, k - 1), ik2 = iso_at(at_l, N, k - 2);
+      z0l[u] = (ik || ik2) ? z0[kl] : 0.0;
+      z0c[u] = ik1 ? z0[kc] : 0.0;
+      z0r[u] = ik ? z0[kr] : 0.0;
+      Xzl[u] = (ik || ik2) ? Xz[kl] : 0.0;
+      Xzc[u] = ik1 ? Xz[kc] : 0.0;
+      Xzr[u] = ik ? Xz[kr] : 0.0;
+      Yzr[u] = ik ? Yz[kr] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int k = k0 + 128 * u;
+      if (k >= N) continue;
+      uint8_t flag = 0;
+      if (k >= 1 && k <= N - 2) {
+        const bool iso_k = iso_at(at_l, N, k), iso_km1 = iso_at(at_l, N, k - 1),
+                   iso_km2 = iso_at(at_l, N, k - 2);
+        const bool l_mod = iso_k || iso_km2;
+        const double m_l = l_mod ? z0l[u] : m0l[u];
+        const double fsmax_l = l_mod ? Xzl[u] : X0l[u];      // FindSddMax(k-1, m_l)
+        const double m_c = iso_km1 ? z0c[u] : m0c[u];
+        const double X_c = iso_km1 ? Xzc[u] : X0c[u];
+        const double Y_c = iso_km1 ? Xzc[u] : Y0c[u];
+        const double m_r = iso_k ? z0r[u] : m0r[u];
+        const double Y_r = iso_k ? Xzr[u] : Y0r[u];
+        const double fsmin_r = iso_k ? Yzr[u] : Y0r[u];      // FindSddMin(k+1, m_r)
+        const double sd2p = (m_r - m_c) / ds;
+        const double sd2p_min = 2 * Y_c;
+        const double sd2p_max = 2 * X_c;
+        const bool sink_or_source = (sd2p < sd2p_min) || (sd2p > sd2p_max);
+        const bool skipped_sdd = (X_c > 0) && (Y_r < 0);
+        const bool skipped_sd2 = (m_c > m_l - kTiny) && (m_c > m_r - kTiny);
+        if ((skipped_sd2 || skipped_sdd) && sink_or_source) {
+          const double fw = m_l + 2.0 * ds * fsmax_l;  // OneForwardExtremalStep(k-1, m_l), .cc:753-759
+          const double bw = m_r - 2.0 * ds * fsmin_r;  // OneBackwardExtremalStep(k+1, m_r), .cc:761-767
+          double mn = z0[k];                           // rare: loaded here
+          if (fw < mn) mn = fw;
+          if (bw < mn) mn = bw;
+          ws.fix_val[pb + k] = (0.0 < mn) ? mn : 0.0;
+          flag = 1;
+        }
+      }
+      ff_l[k] = flag;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  TPAMD_ACC(21, tp0);
+
+  // passes 3 and 4 (.cc:1432-1484): final boundary value, its sdd range, classification.
+  // final value of element j+1 (the last writer among the deferred fixes, see k_boundary_final)
+  // is formed from unconditionally loaded candidates.
+  for (int base = 256 * w; base < N; base += 512) {
+    double m0c[U], z0c[U], X0c[U], Y0c[U], Xzc[U], Yzc[U], fvc[U], m0n[U], z0n[U], fvn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int j = base + 64 * u + lane;
+      const int jc = cl(j), jn = cl(j + 1);
+      m0c[u] = m0[jc]; z0c[u] = z0[jc]; X0c[u] = X0[jc]; Y0c[u] = Y0[jc];
+      m0n[u] = m0[jn]; z0n[u] = z0[jn];
+      // sparse: re-fitted values next to isolated points, deferred-fix values where flagged
+      const bool near_iso = iso_at(at_l, N, jc - 1) || iso_at(at_l, N, jc + 1);
+      Xzc[u] = near_iso ? Xz[jc] : 0.0;
+      Yzc[u] = near_iso ? Yz[jc] : 0.0;
+      fvc[u] = ff_l[jc] ? fv[jc] : 0.0;
+      fvn[u] = ff_l[jn] ? fv[jn] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int j = base + 64 * u + lane;
+      const bool active = j < N;
+      double m = 0.0, X = 0.0, Y = 0.0, m_next = 0.0;
+      bool refit = false;
+      if (active) {
+        const bool f_next = (j + 1 <= N - 2) && ff_l[j + 1];
+        const bool f_self = ff_l[j];
+        const bool f_prev = (j >= 1) && ff_l[j - 1];
+        const bool iso_p = iso_at(at_l, N, j - 1), iso_n = iso_at(at_l, N, j + 1);
+        if (f_next || (!f_self && f_prev)) {
+          m = z0c[u];
+          if (iso_p || iso_n) { X = Xzc[u]; Y = Yzc[u]; }     // pass 2 was here
+          else refit = true;
+        } else if (f_self) {
+          m = fvc[u];
+          refit = true;
+        } else if (iso_n) {
+          m = z0c[u]; X = Xzc[u]; Y = Yzc[u];
+        } else if (iso_p) {
+          m = z0c[u]; X = Xzc[u]; Y = Xzc[u];      // sic, .cc:1394-1395
+        } else {
+          m = m0c[u]; X = X0c[u]; Y = Y0c[u];
+        }
+        // final value of element j + 1
+        const int jn = j + 1;
+        if (jn <= N - 1) {
+          if (jn + 1 <= N - 2 && ff_l[jn + 1]) m_next = z0n[u];
+          else if (ff_l[jn]) m_next = fvn[u];
+          else if (ff_l[jn - 1]) m_next = z0n[u];
+          else if (iso_at(at_l, N, jn + 1) || iso_at(at_l, N, jn - 1)) m_next = z0n[u];
+          else m_next = m0n[u];
+        }
+        if (!refit) P.finalize(j, m, X, Y, m_next);
+      }
+      if (P.count + 64 > kRefitCap) P.template flush<true>(diag);
+      P.append(refit, j, m, m_next);
+    }
+  }
+  P.template flush<true>(diag);
+  __threadfence_block();
+  __syncthreads();
+  TPAMD_ACC(22, tp0);
 }
 
-// WAVES = 1: one wave runs everything. WAVES = 2: wave 0 runs the backward extremals and
-// the tail, wave 1 the forward extremals; within one switching-point loop the two
-// extremals run concurrently (they are data-independent after the backward extremal's
-// first step, see add_extremal). Both waves keep identical copies of the loop scalars.
-template <int D, int WAVES, int E = 0>
-__global__ void __launch_bounds__(64 * WAVES)
+// Dynamic LDS of one path (bytes):
+//   sd2[N2]*8 | tile rings 2 waves x 2 slots x 32 x R*8 | type copy N (padded to 16) |
+//   exchange words 64 | dirty bitmap | zero-pair bitmap | a_max[16]*8 | reduction scratch 32
+// N2 = N rounded up to even (16-byte alignment of the rings). After the switching-point loop
+// the rings hold one chunk of dt / time values and the type copy holds the list of samples
+// whose qd/qdd are redone (see the tail).
+template <int D, int E = 0>
+struct SweepLds {
+  static constexpr int R = 2 * D + E + 2;
+  static constexpr int kRingDoubles = 2 * 2 * kTileSamples * R;
+  __host__ __device__ static constexpr int n2(int N) { return (N + 1) & ~1; }
+  __host__ __device__ static constexpr int words(int N) { return ((N + 31) / 32 + 1) & ~1; }
+  __host__ __device__ static constexpr int type_bytes(int N) { return ((N + 15) / 16) * 16; }
+  __host__ __device__ static constexpr size_t bytes(int N) {
+    return (size_t)n2(N) * 8 + (size_t)kRingDoubles * 8 + type_bytes(N) + 64 +
+           2 * (size_t)words(N) * 4 + 16 * 8 + 32;
+  }
+};
+template <int D, int E = 0>
+__host__ __device__ inline size_t sweep_joint_lds_bytes(int N) {
+  return SweepLds<D, E>::bytes(N);
+}
+
+// One workgroup of two 64-lane waves per path: wave 0 runs the backward extremals, wave 1 the
+// forward extremals; within one switching-point loop the two extremals run concurrently (they
+// are data-independent after the backward extremal's first step, see add_extremal). Both
+// waves keep identical copies of the loop scalars. qd/qdd are written by the extremals as
+// the backward wave finishes with its share (emit_range); the tail is shared by the two waves.
+template <int D, int E = 0>
+__global__ void __launch_bounds__(128)
 k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
               double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
               int32_t *status_out, double *qd_out, double *qdd_out) {
   extern __shared__ double lds[];
+  typedef JointSweep<D, E> JS;
+  typedef SweepLds<D, E> LL;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63;
-  const int w = (WAVES == 2) ? uniform_i32((int)(threadIdx.x >> 6)) : 0;
+  const int w = uniform_i32((int)(threadIdx.x >> 6));
   const int tid = threadIdx.x;
   const int N = path_samples(ws, b, stride);   // samples of this path; arrays use `stride`
   const size_t pb = (size_t)b * stride;
@@ -833,19 +1240,29 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     }
     return;
   }
-  typedef JointSweep<D, E> JS;
   JS S;
   S.N = N; S.lane = lane;
   S.ds = ws.ds[b];
   S.two_ds = 2.0 * S.ds;
   S.sd2 = lds;
-  S.tiles = lds + N + (size_t)w * 2 * kTileSamples * JS::R;
-  uint8_t *typel = reinterpret_cast<uint8_t *>(lds + N + (size_t)WAVES * 2 * kTileSamples * JS::R);
+  double *ring = lds + LL::n2(N);
+  S.tiles = ring + (size_t)w * 2 * kTileSamples * JS::R;
+  uint8_t *typel = reinterpret_cast<uint8_t *>(ring + LL::kRingDoubles);
   S.typel = typel;
-  int *xchg = reinterpret_cast<int *>(typel + ((N + 15) / 16) * 16);
+  int *xchg = reinterpret_cast<int *>(typel + LL::type_bytes(N));
+  const int nw = LL::words(N);
+  uint32_t *dirty = reinterpret_cast<uint32_t *>(xchg + 16);
+  uint32_t *zero = dirty + nw;
+  double *aml = reinterpret_cast<double *>(zero + nw);
+  double *red = aml + 16;
+  S.dirty = dirty;
+  S.aml = aml;
   S.sdd_g = sdd_out + pb;
   S.m_g = ws.m + pb;
   S.rec = src.q12 + pb * JS::R;
+  S.qd_g = qd_out ? qd_out + pb * D : nullptr;
+  S.qdd_g = qdd_out ? qdd_out + pb * D : nullptr;
+  S.end_idx = 0;
   S.tag0 = -1; S.tag1 = -1;
   constexpr int C = 2 * D + E;
   const double *lim_lo = src.lim + (size_t)b * 2 * C, *lim_hi = lim_lo + C;
@@ -907,46 +1324,69 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 
   double *sd2 = S.sd2;
   const double sd_start = ws.sd_start[b];
-  const uint8_t *type_g = ws.type + pb;
-  for (int i = tid; i < N; i += 64 * WAVES) {
+#ifdef TPAMD_DIAG
+  long long(&diag)[24] = S.diag;
+  for (int k = 0; k < 24; k++) diag[k] = 0;
+#define TPAMD_DIAG_PTR S.diag
+#else
+#define TPAMD_DIAG_PTR nullptr
+#endif
+  // CalculateBoundary passes 2-4 for this path; scratch in the LDS the sweep uses afterwards
+  // (flags in the sd2 array, re-fit values in the tile rings)
+  boundary_passes_for_path<D, E>(src, ws, b, N, stride, tid, reinterpret_cast<uint8_t *>(sd2),
+                           reinterpret_cast<uint8_t *>(sd2) + LL::type_bytes(N),
+                           reinterpret_cast<char *>(ring), typel, ws.keep_boundary != 0,
+                           TPAMD_DIAG_PTR);
+  for (int i = tid; i < N; i += 128) {
     sd2[i] = qnan();
     S.sdd_g[i] = qnan();
-    typel[i] = type_g[i];
   }
+  for (int i = tid; i < 2 * nw; i += 128) dirty[i] = 0u;   // dirty and zero-pair bitmaps
+  if (tid < D) aml[tid] = ws.amax ? ws.amax[(size_t)b * D + tid] : 0.0;
   __syncthreads();
-  if (tid == 0) { sd2[0] = sd_start * sd_start; sd2[N - 1] = 0; }
+  if (tid == 0) {
+    xchg[2] = 0;
+    xchg[6] = 0;
+    sd2[0] = sd_start * sd_start;
+    sd2[N - 1] = 0;
+  }
   __syncthreads();
 
   int status = 0;
   int iforw_lo = 0, iback_hi = N - 1, iback_lo, iforw_hi, icrit, icrit_lo, icrit_hi;
   typename JS::Prefetch pf;
   pf.tag = -1;
-#ifdef TPAMD_DIAG
-  long long(&diag)[16] = S.diag;
-  for (int k = 0; k < 16; k++) diag[k] = 0;
-#endif
   TPAMD_T0(t_all);
   // First pair: the forward extremal from 0 may run into the backward one from N-1, so the
   // two are sequential (time_optimal_path_timing.cc:325-326).
-  if (WAVES == 1) {
-    iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi, pf));
-    iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo, pf));
-  } else {
-    if (w == 0) {
-      const int r = S.template add_extremal<false>(iback_hi, pf);
-      if (lane == 0) xchg[0] = r;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (w == 1) {
-      const int r = S.template add_extremal<true>(iforw_lo, pf);
-      if (lane == 0) xchg[1] = r;
-    }
-    __threadfence_block();
-    __syncthreads();
-    iback_lo = uniform_i32(xchg[0]);
-    iforw_hi = uniform_i32(xchg[1]);
+  // qd/qdd bookkeeping of wave 0: samples below emitted_hi and from upper_lo up have been
+  // written (see emit_range)
+  int emitted_hi = 0, upper_lo = N;
+  if (w == 0) {
+    const int r = S.template add_extremal<false>(iback_hi, pf);
+    if (lane == 0) xchg[0] = r;
   }
+  __threadfence_block();
+  __syncthreads();
+  if (w == 1) {
+    const int r = S.template add_extremal<true>(iforw_lo, pf);
+    if (lane == 0) xchg[1] = r;
+  } else {
+    // meanwhile: the region the first backward extremal has just set, short of its lower end
+    // (which the NaN mark below and the connecting forward extremal may still change; what
+    // the latter rewrites is redone in the tail)
+#ifndef TPAMD_EMIT_IN_LOOP
+#define TPAMD_EMIT_IN_LOOP 1
+#endif
+    if (TPAMD_EMIT_IN_LOOP) {
+      upper_lo = min(S.end_idx + 3, N);
+      S.emit_range(upper_lo, N - 1, lane, 64);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  iback_lo = uniform_i32(xchg[0]);
+  iforw_hi = uniform_i32(xchg[1]);
   TPAMD_ACC(9, t_all);   // first pair (sequential)
   icrit_hi = iback_lo;
   if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
@@ -961,24 +1401,28 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   for (int loop = 0; loop < max_loops; loop++) {
     if (iforw_hi >= icrit_hi) break;
     TPAMD_CNT(11);
-    if (WAVES == 2) __syncthreads();   // sd2 writes of the other wave / the NaN mark are visible
+    __syncthreads();   // sd2 writes of the other wave / the NaN mark are visible
     {
       TPAMD_T0(t0);
       icrit = uniform_i32(S.next_critical_point(icrit_lo, icrit_hi, zlast));
       TPAMD_ACC(2, t0);
 #ifdef TPAMD_DIAG
-      if (icrit != S.next_critical_point_literal(icrit_lo, icrit_hi)) TPAMD_CNT(7);
+      {
+        TPAMD_T0(tl_);
+        if (icrit != S.next_critical_point_literal(icrit_lo, icrit_hi)) TPAMD_CNT(7);
+        TPAMD_ACC(18, tl_);
+      }
 #endif
     }
     if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
     if (icrit >= 1) {
       // the tile this wave's extremal starts in: its loads fly together with the loads of
       // the boundary values below instead of after them
-      const int ts = ((WAVES == 2 && w == 1) ? icrit : icrit - 1) / kTileSamples;
+      const int ts = ((w == 1) ? icrit : icrit - 1) / kTileSamples;
       const int tag = (ts & 1) ? S.tag1 : S.tag0;
       if (tag != ts && pf.tag != ts) S.issue_tile_loads(ts, pf);
     }
-    if (WAVES == 2) __syncthreads();   // both waves finished reading sd2 before the marks below
+    __syncthreads();   // both waves finished reading sd2 before the marks below
     if (icrit > 0 && icrit < N - 1 && w == 0) S.put_sd2(icrit, m_g[icrit]);
     if (icrit < 1) { status = 10; break; }
     if (m_g[icrit - 1] <= m_g[icrit]) {
@@ -988,107 +1432,326 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
       iback_hi = icrit;
     }
     iforw_lo = icrit;
-    if (WAVES == 1) {
-      {
-        TPAMD_T0(t0);
-        iback_lo = uniform_i32(S.template add_extremal<false>(iback_hi, pf));
-        TPAMD_ACC(1, t0);
-      }
-      {
-        TPAMD_T0(t0);
-        iforw_hi = uniform_i32(S.template add_extremal<true>(iforw_lo, pf));
-        TPAMD_ACC(0, t0);
-      }
-    } else {
-      __syncthreads();                 // A: the marks are visible to the forward wave
+    __syncthreads();                 // A: the marks are visible to the forward wave
+    {
+      TPAMD_T0(t0);
       if (w == 0) {
-        TPAMD_T0(t0);
         const int r = S.template add_extremal<false>(iback_hi, pf, /*pair_signal=*/true);   // B inside
         if (lane == 0) xchg[0] = r;
-        TPAMD_ACC(1, t0);
+        // The forward extremal of this loop works on samples >= icrit and usually takes
+        // longer: write qd/qdd for everything below icrit that is new or was changed by this
+        // backward extremal (it ended at end_idx) while waiting for it.
+        // -- but only until that one is done (xchg[6] then holds this loop's number): the
+        // rest waits for the next loop or the tail.
+        TPAMD_T0(te);
+        if (TPAMD_EMIT_IN_LOOP)
+          emitted_hi = uniform_i32(S.emit_range(max(min(S.end_idx - 1, emitted_hi), 0), icrit - 1,
+                                                lane, 64, xchg + 6, loop + 1));
+        TPAMD_ACC(12, te);
       } else {
-        TPAMD_T0(t0);
         const int r = S.template add_extremal<true>(iforw_lo, pf, false, /*wait_pair=*/true);   // B inside
-        if (lane == 0) xchg[1] = r;
-        TPAMD_ACC(0, t0);
+        if (lane == 0) {
+          xchg[1] = r;
+          *reinterpret_cast<volatile int *>(xchg + 6) = loop + 1;
+        }
       }
-      __threadfence_block();
-      __syncthreads();                 // C
-      iback_lo = uniform_i32(xchg[0]);
-      iforw_hi = uniform_i32(xchg[1]);
+      TPAMD_ACC(0, t0);
     }
+    {
+      TPAMD_T0(t0);
+      __threadfence_block();
+      __syncthreads();               // C
+      TPAMD_ACC(1, t0);              // time spent waiting for the partner's extremal
+    }
+    iback_lo = uniform_i32(xchg[0]);
+    iforw_hi = uniform_i32(xchg[1]);
     if (iback_lo > icrit_lo) { status = 7; break; }
     icrit_lo = iforw_hi;
   }
   TPAMD_ACC(5, t_all);
-  // sdd_ was written with plain global stores; make it visible to all lanes of the tail
+  if (lane == 0) {
+    if (w == 0) { xchg[4] = emitted_hi; xchg[5] = upper_lo; }
+    else xchg[3] = S.end_idx;          // where the last forward extremal ended
+  }
+  // sdd_, qd, qdd were written with plain global stores; make them visible to both waves
   __threadfence_block();
   __syncthreads();
-#ifdef TPAMD_DIAG
-  if (lane == 0 && ws.diag && w == WAVES - 1)
-    for (int k = 0; k < 16; k++)
-      if (WAVES == 1 || k == 0 || k >= 8) ws.diag[(size_t)b * 16 + k] = S.diag[k];
-#endif
-  int fstatus = 0;
-  if (w == 0) {
-    TPAMD_T0(t0);
-    fstatus = sweep_tail(src, ws, b, N, stride, lane, status, sd2, S.sdd_g, /*copy_sdd=*/false, t_out,
-                         s_out, sd_out, sdd_out, lei_out, dtmax_out, status_out);
-    TPAMD_ACC(3, t0);
-  }
-#ifdef TPAMD_DIAG
-  if (w == 0 && lane == 0 && ws.diag)
-    for (int k = 0; k < 16; k++)
-      if (WAVES == 1 || (k != 0 && k < 8)) ws.diag[(size_t)b * 16 + k] = S.diag[k];
-#endif
-  // Planner epilogue (path_timing_trajectory.cc:458-472) by all lanes of the block:
-  // qd = q' sd, qdd = clamp(q' sdd + q'' sd^2, +-a_max). sd and sdd are read back from the
-  // output rows the tail has just written.
-  if (qd_out == nullptr && qdd_out == nullptr) return;
-  if (WAVES == 2) {
-    if (w == 0 && lane == 0) xchg[0] = fstatus;
-    __threadfence_block();
-    __syncthreads();
-    fstatus = uniform_i32(xchg[0]);
-  } else {
-    tail_sync();
-  }
-  if (fstatus != 0) return;
+
+  // ---------------------------------------------------------------------------------------
+  // Tail (time_optimal_path_timing.cc:398-477), shared by the two waves. `status` is uniform
+  // over the workgroup (both waves computed it from the same exchanged values).
+  // ---------------------------------------------------------------------------------------
+  TPAMD_T0(t_tail);
+  const double ds = S.ds;
+  double *sdd = S.sdd_g;
   {
-    const double *am_g = ws.amax + (size_t)b * D;
-    const f64x2 *rec2 = reinterpret_cast<const f64x2 *>(S.rec);
-    const int total = N * D;
-    constexpr int kBatch = 16;   // loads in flight per lane (the loop is latency-bound otherwise)
-    constexpr int kStep = 64 * WAVES;
-    for (int e0 = tid; e0 < total; e0 += kStep * kBatch) {
-      f64x2 pr[kBatch];
-      double v[kBatch], a[kBatch], am[kBatch];
+    // a sample never reached by an extremal: no solution (.cc:400-403)
+    int has_nan = 0;
+    if (status == 0)
+      for (int idx = tid; idx < N; idx += 128)
+        if (isnan(sd2[idx])) has_nan = 1;
+    if (has_nan) xchg[2] = 1;           // zeroed at set-up; every writer stores the same value
+    __syncthreads();
+    if (status == 0 && xchg[2] != 0) status = 8;
+  }
+  if (status == 0) {
+    // sdd at extremal intersections (.cc:404-411, ComputeSddAtIntersection :722-751 for one
+    // sample alone); four independent loads per thread in flight
+    for (int base = 0; base < N; base += 512) {
+      double cur[4];
 #pragma unroll
-      for (int u = 0; u < kBatch; u++) {
-        const int e = min(e0 + u * kStep, total - 1);
-        const int i = e / D;
-        const int d = e - i * D;
-        pr[u] = rec2[(size_t)i * (JS::R / 2) + d];
-        v[u] = sd_out[pb + i];
-        a[u] = sdd_out[pb + i];
-        am[u] = am_g[d];
+      for (int u = 0; u < 4; u++) cur[u] = sdd[min(base + 128 * u + tid, N - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int idx = base + 128 * u + tid;
+        if (idx < N && isnan(cur[u])) {
+          const auto r = src.at(b, stride, idx);
+          const double s2 = sd2[idx];
+          const bool has_next = idx < N - 1, has_prev = idx > 0;
+          double res = 0.0;
+          bool done = false;
+          if (has_next && has_prev) {
+            const double c = 0.25 / ds * (sd2[idx + 1] - sd2[idx - 1]);
+            if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+          }
+          if (!done && has_next) {
+            const double c = 0.5 / ds * (sd2[idx + 1] - s2);
+            if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+          }
+          if (!done && has_prev) {
+            const double c = 0.5 / ds * (s2 - sd2[idx - 1]);
+            if (rows_valid(r, C, c, s2)) { res = c; done = true; }
+          }
+          sdd[idx] = res;
+          atomicOr(&dirty[idx >> 5], 1u << (idx & 31));
+        }
       }
+    }
+    // start acceleration if admissible (.cc:413-416): rows over the lanes of wave 0
+    if (w == 0) {
+      const double sdd_start = ws.sdd_start[b];
+      const auto r0 = src.at(b, stride, 0);
+      const double s20 = sd2[0];
+      bool bad = false;
+      for (int i = lane; i < C; i += 64) {
+        const double v = r0.a(i) * sdd_start + r0.b(i) * s20;
+        if (v + kTiny < r0.lo(i) || v - kTiny > r0.hi(i)) bad = true;
+      }
+      if (!__any(bad) && lane == 0) {
+        sdd[0] = sdd_start;
+        atomicOr(&dirty[0], 1u);
+      }
+    }
+    if (sd2[N - 1] != 0) status = 9;    // .cc:422-428
+  }
+  if (status != 0) {
+    if (tid == 0) {
+      status_out[b] = status;
+      if (lei_out) lei_out[b] = 0;
+      if (dtmax_out) dtmax_out[b] = -1.0;
+    }
+#ifdef TPAMD_DIAG
+    if (lane == 0 && ws.diag)
+      for (int k = 0; k < 24; k++) ws.diag[(size_t)b * 48 + 24 * w + k] = S.diag[k];
+#endif
+    return;
+  }
+  __threadfence_block();
+  __syncthreads();                      // the filled-in sdd values are visible to both waves
+  {
+    // qd/qdd the loop left: from the backward wave's frontier up to the region written during
+    // the first pair, or as far as the connecting forward extremal rewrote that region
+    const int e_hi = uniform_i32(xchg[4]), u_lo = uniform_i32(xchg[5]);
+    const int f_end = uniform_i32(xchg[3]);
+    S.emit_range(e_hi, min(max(u_lo - 1, f_end + 1), N - 1), tid, 128);
+  }
+  TPAMD_ACC(13, t_tail);
+  const double t0v = ws.t_start[b];
+  const double s0 = ws.s_start[b], s1 = ws.s_end[b];
+  double *tl = ring;                    // one chunk of dt, then time, values
+  constexpr int kCap = LL::kRingDoubles;
+  double tprev = t0v;                   // time_[base - 1] (wave 0)
+  double dtmax = 0.0;
+  for (int base = 0; base < N; base += kCap) {
+    const int n = min(kCap, N - base);
+    const bool last_chunk = base + kCap >= N;
+    TPAMD_T0(t_a);
+    // (a) every sample independently: sd = sqrt(sd2) (.cc:420), the time increment of the
+    //     pair (idx-1, idx) (.cc:450-452), s (.cc:540-547), the copies of sd2
+    for (int k = tid; k < n; k += 128) {
+      const int idx = base + k;
+      const double s2 = sd2[idx];
+      const double sdv = sqrt(s2);
+      double dt = 0.0;
+      if (idx >= 1) {
+        const double s2p = sd2[idx - 1];
+        if ((s2p > 0) || (s2 > 0)) {
+          dt = 2.0 * ds / (sqrt(s2p) + sdv);
+        } else {
+          // stationary pair (.cc:463-465): both accelerations become 0 -- after the
+          // last-extremal scan below has read them
+          const uint32_t m0 = 1u << ((idx - 1) & 31), m1 = 1u << (idx & 31);
+          atomicOr(&zero[(idx - 1) >> 5], m0); atomicOr(&dirty[(idx - 1) >> 5], m0);
+          atomicOr(&zero[idx >> 5], m1);       atomicOr(&dirty[idx >> 5], m1);
+        }
+      }
+      tl[k] = dt;
+      sd_out[pb + idx] = sdv;
+      s_out[pb + idx] = (idx == N - 1) ? s1 : ds * idx + s0;
+      ws.sd2[pb + idx] = s2;
+      if (ws.sd2_out) ws.sd2_out[pb + idx] = s2;
+      if (dt > dtmax) dtmax = dt;
+    }
+    __syncthreads();
+    TPAMD_ACC(16, t_a);
+    TPAMD_T0(t_b);
+    if (w == 0) {
+      // (b) the time integral, strictly left to right (.cc:453-454): one dependent add per
+      //     sample, every lane the same arithmetic, in place
+      double t = tprev;
+      f64x2 *tl2 = reinterpret_cast<f64x2 *>(tl);
+      int k = 0;
+      constexpr int kBlk = 8;           // pairs per block; the next block's loads are issued
+                                        // before the adds of the current one
+      f64x2 d[kBlk], dn[kBlk];
+      if (2 * kBlk <= n) {
 #pragma unroll
-      for (int u = 0; u < kBatch; u++) {
-        const int e = e0 + u * kStep;
-        if (e < total) {
-          if (qd_out) qd_out[pb * D + e] = pr[u].x * v[u];
-          if (qdd_out) {
-            const double v2 = v[u] * v[u];
-            double acc = pr[u].x * a[u] + pr[u].y * v2;
-            if (acc < -am[u]) acc = -am[u];
-            if (acc > am[u]) acc = am[u];
-            qdd_out[pb * D + e] = acc;
+        for (int i = 0; i < kBlk; i++) d[i] = tl2[i];
+      }
+      for (; k + 2 * kBlk <= n; k += 2 * kBlk) {
+        const bool more = k + 4 * kBlk <= n;
+        if (more) {
+#pragma unroll
+          for (int i = 0; i < kBlk; i++) dn[i] = tl2[(k >> 1) + kBlk + i];
+        }
+#pragma unroll
+        for (int i = 0; i < kBlk; i++) {
+          t = t + d[i].x; d[i].x = t;
+          t = t + d[i].y; d[i].y = t;
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < kBlk; i++) tl2[(k >> 1) + i] = d[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kBlk; i++) d[i] = dn[i];
+      }
+      for (; k < n; k++) {
+        t = t + tl[k];
+        if (lane == 0) tl[k] = t;
+      }
+      tprev = t;
+    } else {
+      // (b') wave 1 meanwhile
+      if (base == 0) {
+        // last_extremal_index_ (.cc:430-445): scan down from N-2 for sdd > 0 or a sample on
+        // the boundary curve
+        int lei = 0;
+        const int start = (1 > N - 2) ? 1 : N - 2;
+        bool found = false;
+        for (int top = start; top >= 1 && !found; top -= 256) {
+          double a[4], mm[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {          // unconditional, independent loads
+            const int ic = max(top - 64 * u - lane, 0);
+            a[u] = sdd[ic];
+            mm[u] = m_g[ic];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int idx = top - 64 * u - lane;
+            const bool hit = (idx >= 1) & ((a[u] > 0.0) | (fabs(sd2[max(idx, 0)] - mm[u]) < kTiny));
+            const unsigned long long mask = __ballot(hit);
+            if (mask && !found) { lei = top - 64 * u - (__ffsll((long long)mask) - 1); found = true; }
+          }
+        }
+        if (lane == 0 && lei_out) lei_out[b] = lei;
+      }
+      if (last_chunk) {
+        // zero acceleration across stationary pairs (.cc:463-465)
+        for (int wi = lane; wi < nw; wi += 64) {
+          uint32_t zb = zero[wi];
+          while (zb) {
+            const int i = __ffs((int)zb) - 1;
+            sdd[wi * 32 + i] = 0.0;
+            zb &= zb - 1u;
+          }
+        }
+        __threadfence_block();
+        // qd/qdd of the samples the extremals could not finish (starts, ends, intersections,
+        // filled-in or zeroed accelerations), from the final sd2 and sdd
+        if (S.emitting()) {
+          int *list = reinterpret_cast<int *>(typel);
+          const int list_cap = LL::type_bytes(N) / 4;
+          int count = 0;
+          bool all = false;
+          for (int wb = 0; wb < nw; wb += 64) {
+            const int wi = wb + lane;
+            uint32_t db = (wi < nw) ? dirty[wi] : 0u;
+            const int c = __popc(db);
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+              const int o = __shfl_up(incl, off, 64);
+              if (lane >= off) incl += o;
+            }
+            const int total = count + __shfl(incl, 63, 64);
+            if (total > list_cap) { all = true; break; }     // (uniform) redo every sample
+            int pos = count + incl - c;
+            while (db) {
+              const int i = __ffs((int)db) - 1;
+              list[pos++] = wi * 32 + i;
+              db &= db - 1u;
+            }
+            count = total;
+          }
+          JS::wave_lds_sync();
+          constexpr int PER = 64 / D;          // samples per pass, one lane per (sample, joint)
+          constexpr int U = 4;                 // passes in flight
+          const int g = lane / D, d = lane - g * D;
+          const f64x2 *rec2 = reinterpret_cast<const f64x2 *>(S.rec);
+          const int total = all ? N : count;
+          for (int k0 = 0; k0 < total; k0 += PER * U) {
+            f64x2 pr[U];
+            double s2v[U], av[U];
+            int id[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              const int k = k0 + u * PER + g;
+              ok[u] = (g < PER) && (k < total);
+              const int kk = ok[u] ? k : k0;
+              id[u] = all ? kk : list[kk];
+              pr[u] = rec2[(size_t)id[u] * (JS::R / 2) + d];
+              s2v[u] = sd2[id[u]];
+              av[u] = sdd[id[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+              if (ok[u]) S.emit_value(id[u], d, pr[u], sqrt(s2v[u]), av[u], aml[d]);
           }
         }
       }
     }
+    TPAMD_ACC(17, t_b);
+    __syncthreads();
+    // (c) the chunk's time samples, coalesced
+    for (int k = tid; k < n; k += 128) t_out[pb + base + k] = tl[k];
+    if (!last_chunk) __syncthreads();   // before the next chunk reuses the buffer
   }
+  dtmax = wave_max_f64(dtmax);
+  if (lane == 0) red[w] = dtmax;
+  __syncthreads();
+  if (tid == 0) {
+    status_out[b] = 0;
+    if (dtmax_out) dtmax_out[b] = (red[0] > red[1]) ? red[0] : red[1];
+  }
+  TPAMD_ACC(3, t_tail);
+  TPAMD_ACC(15, t_all);
+#ifdef TPAMD_DIAG
+  if (lane == 0 && ws.diag)
+    for (int k = 0; k < 24; k++) ws.diag[(size_t)b * 48 + 24 * w + k] = S.diag[k];
+#endif
 }
 
 }  // namespace tpamd

@@ -126,7 +126,7 @@ ABI_SYMBOLS = [
     "tpamd_time_cartesian_paths_device", "tpamd_time_cartesian_paths_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
     "tpamd_resample_uniform_host", "tpamd_resample_skip_device", "tpamd_resample_skip_host",
-    "tpamd_debug_copy_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
+    "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
     "tpamd_profile_mean_ms", "tpamd_profile_kernel_name", "tpamd_profile_num_kernels",
 ]
 
@@ -195,6 +195,7 @@ def load_library():
     L.tpamd_resample_skip_host.argtypes = [vp, C.POINTER(_ResampleArgs)]
     L.tpamd_debug_copy_boundary.restype = i
     L.tpamd_debug_copy_boundary.argtypes = [vp, i, i] + [vp] * 6
+    L.tpamd_debug_keep_boundary.argtypes = [vp, i]
     L.tpamd_debug_copy_diag.restype = i
     L.tpamd_debug_copy_diag.argtypes = [vp, i, vp]
     L.tpamd_profile_reset.argtypes = [vp]
@@ -382,8 +383,12 @@ class Engine:
             "tpamd_debug_copy_boundary")
         return arr
 
+    def debug_keep_boundary(self, on=True):
+        """Have the fused joint sweep store sdd_max/sdd_min/type for debug_boundary()."""
+        self._lib.tpamd_debug_keep_boundary(self._h, 1 if on else 0)
+
     def debug_diag(self, B):
-        out = np.zeros((B, 16), dtype=np.int64)
+        out = np.zeros((B, 48), dtype=np.int64)
         _check(self._lib.tpamd_debug_copy_diag(self._h, B, _ptr(out)), "tpamd_debug_copy_diag")
         return out
 
