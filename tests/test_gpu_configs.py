@@ -255,3 +255,52 @@ def test_fused_boundary_passes_match_the_oracle_stage_by_stage(env, kind, D, N, 
         np.testing.assert_array_equal(bd["sdd_min"][i], p.sdd_min_for_sd2_max)
         np.testing.assert_array_equal(bd["type"][i], p.boundary_type)
     E.close()
+
+
+def test_pipelined_engine_gives_the_same_results_in_order(env):
+    """tpamd_engine_set_pipelining: the sampling/LP kernel of a solve runs on the engine's own
+    stream under the previous solve's sweep (two workspaces). Alternating two different batches
+    (and two shapes) through a pipelined engine must reproduce the unpipelined results bit for
+    bit, each complete when the caller's stream has passed its call."""
+    torch, eng, syn = env["torch"], env["eng"], env["syn"]
+    E1, E2 = eng.Engine(0), eng.Engine(0)
+    E2.set_pipelining(True)
+    cases = []
+    for first, D, N, B in ((0, 7, 900, 96), (5000, 7, 900, 96), (77, 6, 333, 40)):
+        b = syn.make_joint_batch(B, D, N, first_path_index=first)
+        inp = eng.upload_joint_batch(b, env["dev"])
+        ref = eng.alloc_joint_outputs(B, N, D, env["dev"])
+        E1.time_joint_paths(inp, ref, N)
+        cases.append((inp, ref, D, N, B))
+    torch.cuda.synchronize()
+    keys = ("time", "s", "sd", "sdd", "q", "qd", "qdd", "status", "last_extremal_index",
+            "max_time_increment")
+    outs = []
+    order = [0, 1, 0, 2, 1, 2, 0, 0, 1]
+    for k in order:                                   # enqueue everything, synchronise once
+        inp, ref, D, N, B = cases[k]
+        out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+        for name in ("time", "sd", "qdd", "q"):
+            out[name].fill_(-3.0)
+        torch.cuda.synchronize()                      # the fill is done before the call (contract)
+        E2.time_joint_paths(inp, out, N)
+        outs.append(out)
+    torch.cuda.synchronize()
+    for k, out in zip(order, outs):
+        for name in keys:
+            assert torch.equal(out[name], cases[k][1][name]), (k, name)
+    # back to back without host synchronisation in between, outputs reused every other call
+    inp, ref, D, N, B = cases[0]
+    inp1, ref1 = cases[1][0], cases[1][1]
+    a, c = eng.alloc_joint_outputs(B, N, D, env["dev"]), eng.alloc_joint_outputs(B, N, D, env["dev"])
+    for it in range(40):
+        E2.time_joint_paths(inp, a, N)
+        E2.time_joint_paths(inp1, c, N)
+    torch.cuda.synchronize()
+    for name in keys:
+        assert torch.equal(a[name], ref[name]) and torch.equal(c[name], ref1[name]), name
+    E2.set_pipelining(False)
+    E2.time_joint_paths(inp, a, N)
+    torch.cuda.synchronize()
+    assert torch.equal(a["time"], ref["time"])
+    E1.close(); E2.close()

@@ -69,6 +69,16 @@ struct tpamd_engine {
   int profile = 0;             // 0 off, 1 every kernel, 2 the sweep kernel only
   bool force_generic = false;  // TPAMD_FORCE_GENERIC=1: A/B the specialised kernels
   bool keep_boundary = false;  // tpamd_debug_keep_boundary
+  // Pipelined mode (tpamd_engine_set_pipelining): two workspaces used alternately, the front
+  // stage (set-up + sampling/LP kernel) of a joint-space solve runs on the engine's own stream
+  // so that it overlaps the sweep of the previous solve.
+  bool pipelining = false;
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_sweep[2] = {nullptr, nullptr};
+  void *slot_base[2] = {nullptr, nullptr};   // ws_base / ws_bytes of the slot not in use
+  size_t slot_bytes[2] = {0, 0};
+  int slot = 0;                // workspace slot e->ws_base currently refers to
+  int k1_tpb = 0;              // TPAMD_K1_TPB: threads per block of the sampling/LP kernel (A/B)
   // Event timing: pending (start, stop) pairs are folded into acc_ms/acc_n and their events
   // recycled through `pool` once kMaxPendingEvents are outstanding, so a long profiled run
   // holds a bounded number of HIP events.
@@ -133,6 +143,16 @@ int ensure_workspace(tpamd_engine *e, int B, int N, int C) {
   carve_workspace((char *)e->ws_base, B, N, C, &e->ws);
   e->ws.keep_boundary = e->keep_boundary ? 1 : 0;
   return 0;
+}
+
+// Pipelined mode: make workspace slot `slot` the current one (e->ws_base / e->ws_bytes).
+void select_slot(tpamd_engine *e, int slot) {
+  if (slot == e->slot) return;
+  e->slot_base[e->slot] = e->ws_base;
+  e->slot_bytes[e->slot] = e->ws_bytes;
+  e->ws_base = e->slot_base[slot];
+  e->ws_bytes = e->slot_bytes[slot];
+  e->slot = slot;
 }
 
 int ensure_stage(tpamd_engine *e, size_t need) {
@@ -427,6 +447,8 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
   {
     const char *fg = std::getenv("TPAMD_FORCE_GENERIC");
     e->force_generic = fg && fg[0] == '1';
+    const char *tb = std::getenv("TPAMD_K1_TPB");
+    e->k1_tpb = tb ? std::atoi(tb) : 0;
   }
   *out = e;
   return 0;
@@ -438,6 +460,12 @@ void tpamd_engine_destroy(tpamd_engine *e) {
   for (auto *v : {&e->events, &e->pool})
     for (auto &ev : *v) { (void)hipEventDestroy(ev.start); (void)hipEventDestroy(ev.stop); }
   if (e->ws_base) (void)hipFree(e->ws_base);
+  if (e->slot_base[1 - e->slot]) (void)hipFree(e->slot_base[1 - e->slot]);
+  for (int k = 0; k < 2; k++) {
+    if (e->ev_front[k]) (void)hipEventDestroy(e->ev_front[k]);
+    if (e->ev_sweep[k]) (void)hipEventDestroy(e->ev_sweep[k]);
+  }
+  if (e->aux) (void)hipStreamDestroy(e->aux);
   if (e->stage_base) (void)hipFree(e->stage_base);
   if (e->rows_base) (void)hipFree(e->rows_base);
   delete e;
@@ -446,7 +474,12 @@ void tpamd_engine_destroy(tpamd_engine *e) {
 int tpamd_engine_reserve(tpamd_engine *e, int B, int N, int C) {
   if (!e || B <= 0 || N <= 0 || C <= 0) return TPAMD_E_INVALID_ARGUMENT;
   TPAMD_ON_DEVICE(e);
-  return ensure_workspace(e, B, N, C);
+  int rc = ensure_workspace(e, B, N, C);
+  if (rc == 0 && e->pipelining) {       // both workspaces of the pipelined mode
+    select_slot(e, 1 - e->slot);
+    rc = ensure_workspace(e, B, N, C);
+  }
+  return rc;
 }
 
 size_t tpamd_engine_workspace_bytes(const tpamd_engine *e) { return e ? e->ws_bytes : 0; }
@@ -465,6 +498,17 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   TPAMD_ON_DEVICE(e);
   hipStream_t st = (hipStream_t)hip_stream;
   const int C = 2 * D;
+  // Pipelined mode: this solve takes the workspace the previous one did not use, and its front
+  // stage goes to the engine's stream, ordered only behind the sweep that last used this
+  // workspace -- not behind the caller's stream (see tpamd_engine_set_pipelining). A stream that
+  // is being captured into a graph cannot fork into the engine's stream: plain order then.
+  bool piped = e->pipelining;
+  if (piped) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) piped = false;
+  }
+  if (piped) select_slot(e, 1 - e->slot);
+  const int slot = e->slot;
   int rc = ensure_workspace(e, B, N, C);
   if (rc) return rc;
   e->last_B = B; e->last_N = N; e->last_time = out->time;
@@ -472,21 +516,29 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   e->ws.amax = in->max_acceleration;
   const Workspace &ws = e->ws;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;  // 0: per path, max(100, 10 n)
+  hipStream_t fs = st;                  // stream of the front stage
+  if (piped) {
+    fs = e->aux;
+    HIPCHK(hipStreamWaitEvent(fs, e->ev_sweep[slot], 0));
+  }
   {
-    Timer t(e, st, KI_SETUP);
-    hipLaunchKernelGGL(k_setup_joint, dim3((B + 127) / 128), dim3(128), 0, st, B, N, D,
+    Timer t(e, fs, KI_SETUP);
+    hipLaunchKernelGGL(k_setup_joint, dim3((B + 127) / 128), dim3(128), 0, fs, B, N, D,
                        bt->constraint_safety, in->max_velocity, in->max_acceleration,
                        in->path_start, in->delta, in->sd_start, in->sdd_start, in->time_start,
                        ws);
   }
   {
-    Timer t(e, st, KI_SAMPLE_LP);
-    const int tpb = (C <= 28) ? 256 : 128;
+    Timer t(e, fs, KI_SAMPLE_LP);
+    // 128 threads (16 KB of LDS at D = 7) fit next to four resident sweep workgroups of an
+    // earlier solve; 256 otherwise
+    int tpb = (C <= 28 && !piped) ? 256 : 128;
+    if (e->k1_tpb == 64 || e->k1_tpb == 128 || e->k1_tpb == 256) tpb = e->k1_tpb;
     const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)D * tpb) * 8;
     if (lds > 160 * 1024) return TPAMD_E_UNSUPPORTED;
     const dim3 grid((N + tpb - 1) / tpb, B);
 #define TPAMD_K1(DD)                                                                         \
-  hipLaunchKernelGGL((k_sample_lp_joint<1, DD>), grid, dim3(tpb), lds, st, N, D, P, in->knots, \
+  hipLaunchKernelGGL((k_sample_lp_joint<1, DD>), grid, dim3(tpb), lds, fs, N, D, P, in->knots, \
                      in->control_points, out->q, ws)
     if (D == 7 && !e->force_generic) TPAMD_K1(7);
     else if (D == 6 && !e->force_generic) TPAMD_K1(6);
@@ -497,6 +549,10 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
     else if (D == 8 && !e->force_generic) TPAMD_K1(8);
     else TPAMD_K1(0);
 #undef TPAMD_K1
+  }
+  if (piped) {
+    HIPCHK(hipEventRecord(e->ev_front[slot], fs));
+    HIPCHK(hipStreamWaitEvent(st, e->ev_front[slot], 0));
   }
   JointSource src;
   src.q12 = ws.q12; src.lim = ws.lim; src.D = D;
@@ -510,7 +566,31 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
                        D, ws.q12, out->sd, out->sdd, in->max_acceleration, out->status, ws.ns,
                        out->qd, out->qdd);
   }
+  if (piped) HIPCHK(hipEventRecord(e->ev_sweep[slot], st));
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tpamd_engine_set_pipelining(tpamd_engine *e, int on) {
+  if (!e) return TPAMD_E_INVALID_ARGUMENT;
+  TPAMD_ON_DEVICE(e);
+  if (on && !e->aux) {
+    // lowest priority: the front stage of the NEXT solve fills what the running sweep leaves
+    // free; it must not take workgroup slots from a sweep that is being dispatched
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const char *pr = std::getenv("TPAMD_AUX_PRIORITY");   // A/B: "high", "default"
+    int prio = least;
+    if (pr && pr[0] == 'h') prio = greatest;
+    if (pr && pr[0] == 'd') prio = 0;
+    HIPCHK(hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, prio));
+    for (int k = 0; k < 2; k++) {
+      HIPCHK(hipEventCreateWithFlags(&e->ev_front[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_sweep[k], hipEventDisableTiming));
+    }
+  }
+  if (!on && e->pipelining) HIPCHK(hipStreamSynchronize(e->aux));
+  e->pipelining = on != 0;
   return 0;
 }
 
