@@ -242,6 +242,47 @@ int tpo_time_cartesian_batch(int B, const double *q, const double *J, int N, int
                              double *t, double *s, double *sd, double *sdd, double *qd,
                              double *qdd, int *last_extremal_index, int *status);
 
+/* ------------------------------------------------ receding-horizon planner */
+
+/* PathTimingTrajectory::Plan (path_timing_trajectory.cc:579-684) for ONE planner with a
+ * TimeableJointSplinePath, restated in tp_oracle_plan.c on top of the single-window functions
+ * above. Times and durations are int64 nanoseconds (trajectory_planning/time.h:22-29). */
+typedef struct tpo_planner tpo_planner;
+enum { TPO_PATH_NONE = 0, TPO_PATH_NEW = 1, TPO_PATH_MODIFIED = 2, TPO_PATH_SAMPLED = 3 };  /* timeable_path.h:94-103 */
+enum {
+  TPO_PLAN_OK = 0,
+  TPO_PLAN_FAILED_PRECONDITION = 1, /* no path (.cc:582-584), nothing to connect to */
+  TPO_PLAN_OUT_OF_RANGE = 2,        /* start beyond the previous plan (.cc:503-510, :296-298) */
+  TPO_PLAN_INVALID_ARGUMENT = 3,    /* time order (.cc:517-535), duration (:313-317), start velocity (:387-392) */
+  TPO_PLAN_INTERNAL = 4,            /* solver set-up / optimisation failed (.cc:394-417), :299-303 */
+  TPO_PLAN_DEADLINE_EXCEEDED = 5    /* planning-loop limit (.cc:655-658) */
+};
+/* sampling_method: 0 kUniformlyInTime, 1 kSkipSamplesCloserThanTimeStep */
+tpo_planner *tpo_planner_create(int D, int N, double delta, double safety, int64_t time_step_ns,
+                                int sampling_method, int max_planning_iterations,
+                                double max_initial_velocity_error);
+void tpo_planner_destroy(tpo_planner *p);
+void tpo_planner_set_limits(tpo_planner *p, const double *vmax, const double *amax);
+void tpo_planner_set_initial_velocity(tpo_planner *p, const double *v);
+/* the spline of the path and its state (TPO_PATH_NEW after SetWaypoints, TPO_PATH_MODIFIED
+ * after SwitchToWaypointPath) */
+void tpo_planner_set_spline(tpo_planner *p, const double *knots, int num_knots, const double *cps,
+                            int num_points, int state);
+int tpo_planner_plan(tpo_planner *p, int64_t start_ns, int64_t time_horizon_ns);
+int tpo_planner_num_samples(const tpo_planner *p);
+const double *tpo_planner_time(const tpo_planner *p);
+const double *tpo_planner_positions(const tpo_planner *p);     /* [M][D] */
+const double *tpo_planner_velocities(const tpo_planner *p);
+const double *tpo_planner_accelerations(const tpo_planner *p);
+const double *tpo_planner_path_parameter(const tpo_planner *p);
+const double *tpo_planner_path_velocity(const tpo_planner *p);
+const double *tpo_planner_path_acceleration(const tpo_planner *p);
+int64_t tpo_planner_end_time(const tpo_planner *p);
+int64_t tpo_planner_final_decel_start(const tpo_planner *p);
+int tpo_planner_target_reached(const tpo_planner *p);
+int tpo_planner_windows(const tpo_planner *p);   /* timing windows computed by the last plan */
+int tpo_planner_path_state(const tpo_planner *p);
+
 #ifdef __cplusplus
 }
 #endif

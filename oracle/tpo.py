@@ -28,10 +28,9 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force=False):
     so = os.path.join(_HERE, "libtp_oracle.so")
-    src = os.path.join(_HERE, "tp_oracle.c")
-    hdr = os.path.join(_HERE, "tp_oracle.h")
+    deps = [os.path.join(_HERE, f) for f in ("tp_oracle.c", "tp_oracle_plan.c", "tp_oracle.h")]
     if force or not os.path.exists(so) or any(
-            os.path.getmtime(f) > os.path.getmtime(so) for f in (src, hdr)):
+            os.path.getmtime(f) > os.path.getmtime(so) for f in deps):
         subprocess.check_call(["make", "-C", _HERE, "libtp_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return so
@@ -386,3 +385,76 @@ def time_cartesian_batch(q, J, vmax, amax, vtrans, vrot, path_start, delta, sd_s
                                    int(nthreads), t, s, sd, sdd, qd, qdd, lei, status)
     return dict(t=t, s=s, sd=sd, sdd=sdd, q=q, qd=qd, qdd=qdd, last_extremal_index=lei,
                 status=status)
+
+
+# ------------------------------------------------------- receding-horizon planner
+class Planner:
+    """tp_oracle_plan.c: PathTimingTrajectory::Plan (path_timing_trajectory.cc:579-684) for one
+    planner with a joint-space spline path. Times in integer nanoseconds."""
+    STATUS = {0: "ok", 1: "failed_precondition", 2: "out_of_range", 3: "invalid_argument",
+              4: "internal", 5: "deadline_exceeded"}
+
+    def __init__(self, D, N, delta=0.005, safety=0.8, time_step_ns=4_000_000, skip=False,
+                 max_planning_iterations=10000, max_initial_velocity_error=1e-3):
+        L = lib()
+        vp, i, d, i64 = C.c_void_p, C.c_int, C.c_double, C.c_int64
+        L.tpo_planner_create.restype = vp
+        L.tpo_planner_create.argtypes = [i, i, d, d, i64, i, i, d]
+        L.tpo_planner_destroy.argtypes = [vp]
+        L.tpo_planner_set_limits.argtypes = [vp, _dp, _dp]
+        L.tpo_planner_set_initial_velocity.argtypes = [vp, _dp]
+        L.tpo_planner_set_spline.argtypes = [vp, _dp, i, _dp, i, i]
+        L.tpo_planner_plan.restype = i
+        L.tpo_planner_plan.argtypes = [vp, i64, i64]
+        for name in ("num_samples", "target_reached", "windows", "path_state"):
+            getattr(L, "tpo_planner_" + name).restype = i
+            getattr(L, "tpo_planner_" + name).argtypes = [vp]
+        for name in ("end_time", "final_decel_start"):
+            getattr(L, "tpo_planner_" + name).restype = i64
+            getattr(L, "tpo_planner_" + name).argtypes = [vp]
+        for name in ("time", "positions", "velocities", "accelerations", "path_parameter",
+                     "path_velocity", "path_acceleration"):
+            getattr(L, "tpo_planner_" + name).restype = C.POINTER(C.c_double)
+            getattr(L, "tpo_planner_" + name).argtypes = [vp]
+        self._L, self.D, self.N = L, D, N
+        self._p = L.tpo_planner_create(D, N, float(delta), float(safety), int(time_step_ns),
+                                       1 if skip else 0, int(max_planning_iterations),
+                                       float(max_initial_velocity_error))
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            self._L.tpo_planner_destroy(self._p)
+            self._p = None
+
+    def set_limits(self, vmax, amax):
+        self._L.tpo_planner_set_limits(self._p, _f64(vmax), _f64(amax))
+
+    def set_waypoints(self, waypoints, rounding=0.2, state=1):
+        """SetWaypoints: fit the spline (timeable_path_joint_spline.cc:252-292), state kNewPath."""
+        cps, knots = joint_fit_spline(waypoints, rounding)
+        self.set_spline(knots, cps, state)
+        return cps, knots
+
+    def set_spline(self, knots, cps, state=1):
+        knots, cps = _f64(knots), _f64(cps)
+        self._L.tpo_planner_set_spline(self._p, knots, len(knots), cps, cps.shape[0], int(state))
+
+    def plan(self, start_ns, horizon_ns):
+        return self._L.tpo_planner_plan(self._p, int(start_ns), int(horizon_ns))
+
+    def _vec(self, name, width=1):
+        n = self.num_samples * width
+        ptr = getattr(self._L, "tpo_planner_" + name)(self._p)
+        a = np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0)
+        return a.reshape(-1, width) if width > 1 else a
+
+    num_samples = property(lambda self: self._L.tpo_planner_num_samples(self._p))
+    time = property(lambda self: self._vec("time"))
+    positions = property(lambda self: self._vec("positions", self.D))
+    velocities = property(lambda self: self._vec("velocities", self.D))
+    accelerations = property(lambda self: self._vec("accelerations", self.D))
+    path_parameter = property(lambda self: self._vec("path_parameter"))
+    end_time = property(lambda self: self._L.tpo_planner_end_time(self._p))
+    final_decel_start = property(lambda self: self._L.tpo_planner_final_decel_start(self._p))
+    target_reached = property(lambda self: bool(self._L.tpo_planner_target_reached(self._p)))
+    windows = property(lambda self: self._L.tpo_planner_windows(self._p))

@@ -459,6 +459,152 @@ static void TestPlanBatch() {
   }
 }
 
+// Plan / PlanBatch against the oracle's restatement of PathTimingTrajectory::Plan
+// (oracle/tp_oracle_plan.c): same windows, same resampled trajectory, same bookkeeping, bit for
+// bit -- for the reference's planner fixture (path_timing_trajectory_test.cc:112-173: three
+// waypoints, 1000 path samples at the default sampling distance so that the path needs several
+// windows, 4 ms, 750 ms horizon, a replan every 200 ms) with both time sampling methods
+// (including the "already planned enough" erase of path_timing_trajectory.cc:540-575), and for
+// random multi-window 7-joint planners advanced together by PlanBatch.
+static void ComparePlannerWithOracle(const PathTimingTrajectory &pl, const tpo_planner *o, int D) {
+  const int M = tpo_planner_num_samples(o);
+  CHECK((int)pl.GetTime().size() == M);
+  if ((int)pl.GetTime().size() != M) return;
+  const double *t = tpo_planner_time(o), *q = tpo_planner_positions(o), *v = tpo_planner_velocities(o),
+               *a = tpo_planner_accelerations(o), *s = tpo_planner_path_parameter(o);
+  int bad = 0;
+  for (int i = 0; i < M; i++) {
+    if (pl.GetTime()[i] != t[i]) bad++;
+    if (pl.GetPathParameters()[i] != s[i]) bad++;
+    for (int d = 0; d < D; d++) {
+      if (pl.GetPositions()[i][d] != q[(size_t)i * D + d]) bad++;
+      if (pl.GetVelocities()[i][d] != v[(size_t)i * D + d]) bad++;
+      if (pl.GetAccelerations()[i][d] != a[(size_t)i * D + d]) bad++;
+    }
+  }
+  CHECK(bad == 0);
+  CHECK(tpamd::compat::ToUnixNanos(pl.GetEndTime()) == tpo_planner_end_time(o));
+  CHECK(tpamd::compat::ToUnixNanos(pl.GetFinalDecelStart()) == tpo_planner_final_decel_start(o));
+  CHECK(pl.IsTrajectoryAtEnd() == (tpo_planner_target_reached(o) != 0));
+}
+
+static void TestPlanAgainstOracle() {
+  using Method = PathTimingTrajectoryOptions::TimeSamplingMethod;
+  const int64_t kMs = 1000000;
+  for (Method method : {Method::kUniformlyInTime, Method::kSkipSamplesCloserThanTimeStep}) {
+    const int D = 3, N = 1000;
+    auto path = std::make_shared<TimeableJointSplinePath>(JointPathOptions().set_num_dofs(D).set_num_path_samples(N));
+    PathTimingTrajectory planner(PathTimingTrajectoryOptions().SetTimeStep(Milliseconds(4)).SetNumDofs(D)
+                                     .SetNumPathSamples(N).SetTimeSamplingMethod(method));
+    CHECK(planner.SetPath(path).ok());
+    std::vector<VectorXd> wps;
+    for (double sgn : {1.0, -1.0, 1.0}) { VectorXd w(D); w[0] = sgn; w[1] = 2 * sgn; w[2] = 3 * sgn; wps.push_back(w); }
+    CHECK(path->SetWaypoints({wps.data(), wps.size()}).ok());
+    std::vector<double> vmax(D, 1.0), amax(D, 2.0);
+    CHECK(path->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+    CHECK(path->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+    tpo_planner *o = tpo_planner_create(D, N, path->options().delta_parameter(), path->options().constraint_safety(),
+                                        4 * kMs, method == Method::kUniformlyInTime ? 0 : 1, 10000, 1e-3);
+    tpo_planner_set_limits(o, vmax.data(), amax.data());
+    tpo_planner_set_spline(o, path->knots().data(), (int)path->knots().size(), path->packed_control_points().data(),
+                           (int)path->num_control_points(), TPO_PATH_NEW);
+    int64_t start = 0;
+    int loops = 0, windows = 0, erase_only = 0;
+    while (!planner.IsTrajectoryAtEnd() && loops < 200) {
+      const bool ok = planner.Plan(tpamd::compat::FromUnixNanos(start), Milliseconds(750)).ok();
+      const int rc = tpo_planner_plan(o, start, 750 * kMs);
+      CHECK(ok == (rc == TPO_PLAN_OK));
+      if (!ok || rc != TPO_PLAN_OK) break;
+      ComparePlannerWithOracle(planner, o, D);
+      windows += tpo_planner_windows(o);
+      erase_only += tpo_planner_windows(o) == 0;
+      start = std::min<int64_t>(tpo_planner_end_time(o), start + 200 * kMs);
+      loops++;
+    }
+    CHECK(planner.IsTrajectoryAtEnd());
+    CHECK(loops > 5 && windows >= 3);
+    for (int d = 0; d < D; d++) {
+      CHECK(planner.GetVelocities().back()[d] == 0.0);
+      CHECK(std::fabs(planner.GetPositions().back()[d] - wps.back()[d]) < 1e-9);
+    }
+    // the whole path in one call, then a later start well inside the planned horizon: the
+    // "already planned enough" branch only erases (for kSkip: interpolated first sample)
+    auto path2 = std::make_shared<TimeableJointSplinePath>(JointPathOptions().set_num_dofs(D).set_num_path_samples(N));
+    PathTimingTrajectory planner2(PathTimingTrajectoryOptions().SetTimeStep(Milliseconds(4)).SetNumDofs(D)
+                                      .SetNumPathSamples(N).SetTimeSamplingMethod(method));
+    CHECK(planner2.SetPath(path2).ok());
+    CHECK(path2->SetWaypoints({wps.data(), wps.size()}).ok());
+    CHECK(path2->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+    CHECK(path2->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+    tpo_planner *o2 = tpo_planner_create(D, N, path2->options().delta_parameter(), path2->options().constraint_safety(),
+                                         4 * kMs, method == Method::kUniformlyInTime ? 0 : 1, 10000, 1e-3);
+    tpo_planner_set_limits(o2, vmax.data(), amax.data());
+    tpo_planner_set_spline(o2, path2->knots().data(), (int)path2->knots().size(),
+                           path2->packed_control_points().data(), (int)path2->num_control_points(), TPO_PATH_NEW);
+    CHECK(planner2.Plan(tpamd::compat::FromUnixNanos(0), Seconds(1.0e6)).ok());
+    CHECK(tpo_planner_plan(o2, 0, (int64_t)1000000 * 1000 * kMs) == TPO_PLAN_OK);
+    ComparePlannerWithOracle(planner2, o2, D);
+    for (int64_t st : {(int64_t)501 * kMs, (int64_t)1337 * kMs + 12345}) {
+      CHECK(planner2.Plan(tpamd::compat::FromUnixNanos(st), Milliseconds(100)).ok());
+      CHECK(tpo_planner_plan(o2, st, 100 * kMs) == TPO_PLAN_OK);
+      CHECK(tpo_planner_windows(o2) == 0);
+      ComparePlannerWithOracle(planner2, o2, D);
+      if (method == Method::kSkipSamplesCloserThanTimeStep)   // first sample interpolated at the start time
+        CHECK(planner2.GetTime().front() == (double)st / 1e9);
+    }
+    tpo_planner_destroy(o);
+    tpo_planner_destroy(o2);
+  }
+  // several 7-joint planners with random waypoints, advanced together
+  {
+    const int K = 5, D = 7, N = 400;
+    unsigned long long seed = 4242;
+    auto rnd = [&]() { seed = seed * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(seed >> 11) / 9007199254740992.0; };
+    std::vector<std::shared_ptr<TimeableJointSplinePath>> paths(K);
+    std::vector<std::unique_ptr<PathTimingTrajectory>> planners;
+    std::vector<PathTimingTrajectory *> ptrs;
+    std::vector<tpo_planner *> oracles(K);
+    for (int k = 0; k < K; k++) {
+      std::vector<VectorXd> wps;
+      for (int i = 0; i < 4 + k % 3; i++) { VectorXd v(D); for (int d = 0; d < D; d++) v[d] = 5.0 * rnd() - 2.5; wps.push_back(v); }
+      auto probe = std::make_shared<TimeableJointSplinePath>(JointPathOptions().set_num_dofs(D).set_num_path_samples(N));
+      probe->SetWaypoints({wps.data(), wps.size()});
+      const double delta = 0.35 * probe->knots().back() / (N - 1);
+      paths[k] = std::make_shared<TimeableJointSplinePath>(
+          JointPathOptions().set_num_dofs(D).set_num_path_samples(N).set_delta_parameter(delta));
+      std::vector<double> vmax(D), amax(D);
+      for (int d = 0; d < D; d++) { vmax[d] = 1.0 + rnd(); amax[d] = 2.0 + 2.0 * rnd(); }
+      CHECK(paths[k]->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+      CHECK(paths[k]->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+      CHECK(paths[k]->SetWaypoints({wps.data(), wps.size()}).ok());
+      const bool skip = (k % 2) == 1;
+      planners.push_back(std::make_unique<PathTimingTrajectory>(
+          PathTimingTrajectoryOptions().SetNumDofs(D).SetNumPathSamples(N).SetTimeStep(Milliseconds(4))
+              .SetTimeSamplingMethod(skip ? Method::kSkipSamplesCloserThanTimeStep : Method::kUniformlyInTime)));
+      CHECK(planners.back()->SetPath(paths[k]).ok());
+      ptrs.push_back(planners.back().get());
+      oracles[k] = tpo_planner_create(D, N, delta, paths[k]->options().constraint_safety(), 4 * kMs, skip ? 1 : 0,
+                                      10000, 1e-3);
+      tpo_planner_set_limits(oracles[k], vmax.data(), amax.data());
+      tpo_planner_set_spline(oracles[k], paths[k]->knots().data(), (int)paths[k]->knots().size(),
+                             paths[k]->packed_control_points().data(), (int)paths[k]->num_control_points(),
+                             TPO_PATH_NEW);
+    }
+    int64_t start = 3 * 1000 * kMs;
+    for (int round = 0; round < 4; round++) {
+      const auto st = PathTimingTrajectory::PlanBatch(ptrs, tpamd::compat::FromUnixNanos(start),
+                                                      round == 3 ? Seconds(1000.0) : Milliseconds(600));
+      for (int k = 0; k < K; k++) {
+        const int rc = tpo_planner_plan(oracles[k], start, round == 3 ? (int64_t)1000 * 1000 * kMs : 600 * kMs);
+        CHECK(st[k].ok() == (rc == TPO_PLAN_OK));
+        if (st[k].ok() && rc == TPO_PLAN_OK) ComparePlannerWithOracle(*planners[k], oracles[k], D);
+      }
+      start += 150 * kMs;
+    }
+    for (int k = 0; k < K; k++) { CHECK(planners[k]->IsTrajectoryAtEnd()); tpo_planner_destroy(oracles[k]); }
+  }
+}
+
 int main() {
   TestProfileAgainstOracle();
   TestJointPathAndPlanner();
@@ -466,6 +612,7 @@ int main() {
   TestMixedBatch();
   TestCartesianBatch();
   TestPlanBatch();
+  TestPlanAgainstOracle();
   if (g_fail == 0) std::printf("ALL OK\n");
   else std::printf("%d CHECKS FAILED\n", g_fail);
   return g_fail == 0 ? 0 : 1;

@@ -302,6 +302,80 @@ Status PathTimingTrajectory::EndWindow(Window *w) {
   return OkStatus();
 }
 
+// path_timing_trajectory.cc:686-695
+int PathTimingTrajectory::TimeAtPathSamplesLowerIndex(int starting_index, double time) const {
+  const int n = (int)time_at_path_samples_.size();
+  for (int index = starting_index; index < n - 1; ++index)
+    if (time_at_path_samples_[index + 1] > time) return index;
+  return n - 1;
+}
+
+// path_timing_trajectory.cc:709-753 for ONE query time (host control flow of Plan; the resampling
+// of whole trajectories runs on the GPU with the same a + t (b - a) blend).
+PathTimingTrajectory::InterpolationResult PathTimingTrajectory::InterpolateAtTime(double time_sec,
+                                                                                  int lower_index) const {
+  const size_t D = options_.GetNumDofs();
+  InterpolationResult r;
+  r.lower_index = TimeAtPathSamplesLowerIndex(lower_index, time_sec);
+  const int lower = r.lower_index;
+  const int upper = std::min<int>((int)time_at_path_samples_.size() - 1, lower + 1);
+  const double *tm = time_at_path_samples_.data();
+  const double at = std::abs(tm[upper] - tm[lower]) < std::numeric_limits<double>::epsilon()
+                        ? 0.5
+                        : (time_sec - tm[lower]) / (tm[upper] - tm[lower]);
+  auto lerp = [at](double a, double b) { return a + at * (b - a); };
+  const VectorXd &amax = path_->GetMaxJointAcceleration();
+  r.position = VectorXd(D); r.velocity = VectorXd(D); r.acceleration = VectorXd(D);
+  for (size_t d = 0; d < D; d++) {
+    r.position[d] = lerp(position_at_path_samples_[lower * D + d], position_at_path_samples_[upper * D + d]);
+    r.velocity[d] = lerp(velocity_at_path_samples_[lower * D + d], velocity_at_path_samples_[upper * D + d]);
+    const double a = lerp(acceleration_at_path_samples_[lower * D + d], acceleration_at_path_samples_[upper * D + d]);
+    r.acceleration[d] = std::min(std::max(a, -amax[d]), amax[d]);
+  }
+  r.path_parameter = lerp(path_parameter_at_path_samples_[lower], path_parameter_at_path_samples_[upper]);
+  r.path_parameter_derivative = lerp(path_velocity_at_path_samples_[lower], path_velocity_at_path_samples_[upper]);
+  r.second_path_parameter_derivative =
+      lerp(path_acceleration_at_path_samples_[lower], path_acceleration_at_path_samples_[upper]);
+  return r;
+}
+
+// path_timing_trajectory.cc:868-880
+void PathTimingTrajectory::EraseSamplesUntil(int offset) {
+  if (offset <= 0) return;
+  auto drop = [&](auto &v) { v.erase(v.begin(), v.begin() + std::min<size_t>((size_t)offset, v.size())); };
+  drop(time_); drop(path_parameter_); drop(path_parameter_derivative_);
+  drop(second_path_parameter_derivative_); drop(positions_); drop(velocities_); drop(accelerations_);
+}
+
+// path_timing_trajectory.cc:540-575
+void PathTimingTrajectory::EraseTrajectoryBefore(Time time) {
+  const double time_sec = TimeToSec(time);
+  if (time_.empty() || time_sec < time_.front()) return;
+  switch (options_.GetTimeSamplingMethod()) {
+    case PathTimingTrajectoryOptions::TimeSamplingMethod::kSkipSamplesCloserThanTimeStep: {
+      // number of samples with a time stamp < time_sec (GetSampleCountUntil, :41-44)
+      int smaller = (int)(std::lower_bound(time_.begin(), time_.end(), time_sec) - time_.begin());
+      smaller = std::min<int>(smaller, (int)time_.size() - 1);   // the reference reads time_[smaller] unguarded
+      const InterpolationResult at_time = InterpolateAtTime(time_sec, std::max(smaller, 0));
+      if (time_[smaller] < time_sec + GetMinTimeDeltaToKeep()) EraseSamplesUntil(smaller);
+      else EraseSamplesUntil(smaller - 1);
+      // the first sample sits exactly at the requested time
+      time_.front() = time_sec;
+      positions_.front() = at_time.position;
+      velocities_.front() = at_time.velocity;
+      accelerations_.front() = at_time.acceleration;
+      path_parameter_.front() = at_time.path_parameter;
+      path_parameter_derivative_.front() = at_time.path_parameter_derivative;
+      second_path_parameter_derivative_.front() = at_time.second_path_parameter_derivative;
+    } break;
+    case PathTimingTrajectoryOptions::TimeSamplingMethod::kUniformlyInTime: {
+      const int offset = std::min<int>((int)std::round((time_sec - time_.front()) / time_step_sec_),
+                                       (int)time_.size() - 1);
+      EraseSamplesUntil(offset);
+    } break;
+  }
+}
+
 // path_timing_trajectory.cc:579-630: everything before the window loop.
 Status PathTimingTrajectory::PlanPrologue(Time start, Duration time_horizon, bool *needs_windows) {
   *needs_windows = false;
@@ -313,15 +387,8 @@ Status PathTimingTrajectory::PlanPrologue(Time start, Duration time_horizon, boo
                               (path_->GetState() != TimeablePath::State::kModifiedPath) &&
                               (final_decel_start_ >= start + time_horizon);
   if (!time_.empty() && planned_enough) {
-    // Already planned far enough: drop the uniformly sampled part before `start`
-    // (kUniformlyInTime branch of EraseTrajectoryBefore, path_timing_trajectory.cc:568-573).
-    if (start_sec >= time_.front()) {
-      const int offset = std::min<int>((int)std::round((start_sec - time_.front()) / time_step_sec_),
-                                       (int)time_.size() - 1);
-      auto drop = [&](auto &v) { v.erase(v.begin(), v.begin() + offset); };
-      drop(time_); drop(path_parameter_); drop(path_parameter_derivative_);
-      drop(second_path_parameter_derivative_); drop(positions_); drop(velocities_); drop(accelerations_);
-    }
+    // Already planned far enough: only drop what lies before `start`.
+    EraseTrajectoryBefore(start);
     return OkStatus();
   }
   if (initial_plan_) {

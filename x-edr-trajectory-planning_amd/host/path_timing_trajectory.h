@@ -81,6 +81,16 @@ class PathTimingTrajectory : public TrajectoryPlanner {
                                 std::vector<Window> *windows, const std::vector<size_t> &ids,
                                 std::vector<Status> *status);
   void ClampToTimeStepMultiple(Time *time);
+  // path_timing_trajectory.h (reference) InterpolationResult, InterpolateAtTime :709-753
+  struct InterpolationResult {
+    int lower_index = 0;
+    VectorXd position, velocity, acceleration;
+    double path_parameter = 0, path_parameter_derivative = 0, second_path_parameter_derivative = 0;
+  };
+  InterpolationResult InterpolateAtTime(double time_sec, int lower_index) const;
+  int TimeAtPathSamplesLowerIndex(int starting_index, double time) const;
+  void EraseTrajectoryBefore(Time time);   // :540-575, both time sampling methods
+  void EraseSamplesUntil(int offset);      // :868-880
   ::tpamd::compat::StatusOr<int> GetTimeOffsetAfter(Time time) const;
   Status ResampleTrajectory(double start_sec);
   Status ResampleEquidistantlyInTime(double start_sec);
