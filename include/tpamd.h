@@ -211,6 +211,25 @@ int tpamd_time_cartesian_paths_host(tpamd_engine *engine, const tpamd_cartesian_
                                     const tpamd_cartesian_inputs *in,
                                     const tpamd_path_outputs *out);
 
+/* Pose targets of Cartesian-space paths: what TimeableCartesianSplinePath::SamplePath evaluates
+ * before it calls the IK callback (timeable_path_cartesian_spline.cc:484-503), for B paths at
+ * once: the degree-2 translation spline (BSplineT::EvalCurve, splines/bspline.h:512-536) and the
+ * degree-2 quaternion spline (BSplineQ::EvalCurve, splines/bsplineq.cc:223-244: cumulative basis
+ * :309-317, QuatPower = exp(p log q) :112-146) on a shared knot vector, at
+ * path_start[b] + i * delta[b], i < N; beyond knots.back() - delta the last control pose is
+ * repeated. knots [B][P+3], translation_points [B][P][3], rotation_points [B][P][4] as
+ * (w, x, y, z), poses [B][N][7] = (tx, ty, tz, qw, qx, qy, qz). The IK and Jacobian callbacks
+ * stay with the caller; their results go to tpamd_time_cartesian_paths_*. */
+int tpamd_sample_pose_splines_device(tpamd_engine *engine, int num_paths, int num_samples,
+                                     int num_points, const double *knots,
+                                     const double *translation_points,
+                                     const double *rotation_points, const double *path_start,
+                                     const double *delta, double *poses, void *hip_stream);
+int tpamd_sample_pose_splines_host(tpamd_engine *engine, int num_paths, int num_samples,
+                                   int num_points, const double *knots,
+                                   const double *translation_points, const double *rotation_points,
+                                   const double *path_start, const double *delta, double *poses);
+
 /* Batched TimeOptimalPathProfile::FindMaxSd2Simplex (time_optimal_path_timing.cc:1149-1363)
  * on num_lps independent constraint sets of C rows each ([num_lps][C] arrays);
  * outputs sd2max/sddmax/sd2zero [num_lps]. Host pointers. */

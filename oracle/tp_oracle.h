@@ -242,6 +242,21 @@ int tpo_time_cartesian_batch(int B, const double *q, const double *J, int N, int
                              double *t, double *s, double *sd, double *sdd, double *qd,
                              double *qdd, int *last_extremal_index, int *status);
 
+/* ----------------------------------------------------- quaternion B-splines */
+
+/* splines/bsplineq.cc: QuatLog :112-125, QuatExp :127-134, QuatPower :136-146, BSplineQ::EvalCurve
+ * :223-244 (tp_oracle_quat.c). Quaternions are [w, x, y, z]; points [num_points][4]. */
+void tpo_quat_log(const double *q, double *out);
+void tpo_quat_exp(const double *q, double *out);
+void tpo_quat_power(const double *q, double power, double *out);
+int tpo_bsplineq_eval_curve(const double *knots, int num_knots, int degree, const double *points,
+                            double u, double *quat);
+/* pose targets of TimeableCartesianSplinePath::SamplePath (timeable_path_cartesian_spline.cc:
+ * 484-503): poses [N][7] = (tx, ty, tz, qw, qx, qy, qz) */
+int tpo_sample_pose_spline(const double *knots, int num_knots, const double *translation_points,
+                           const double *rotation_points, int num_points, double path_start,
+                           double delta, int N, double *poses);
+
 /* ------------------------------------------------ receding-horizon planner */
 
 /* PathTimingTrajectory::Plan (path_timing_trajectory.cc:579-684) for ONE planner with a

@@ -28,7 +28,7 @@ _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force=False):
     so = os.path.join(_HERE, "libtp_oracle.so")
-    deps = [os.path.join(_HERE, f) for f in ("tp_oracle.c", "tp_oracle_plan.c", "tp_oracle.h")]
+    deps = [os.path.join(_HERE, f) for f in ("tp_oracle.c", "tp_oracle_plan.c", "tp_oracle_quat.c", "tp_oracle.h")]
     if force or not os.path.exists(so) or any(
             os.path.getmtime(f) > os.path.getmtime(so) for f in deps):
         subprocess.check_call(["make", "-C", _HERE, "libtp_oracle.so"],
@@ -458,3 +458,50 @@ class Planner:
     final_decel_start = property(lambda self: self._L.tpo_planner_final_decel_start(self._p))
     target_reached = property(lambda self: bool(self._L.tpo_planner_target_reached(self._p)))
     windows = property(lambda self: self._L.tpo_planner_windows(self._p))
+
+
+# ------------------------------------------------------------ quaternion splines
+def _q4(fn, q, *extra):
+    out = np.zeros(4)
+    getattr(lib(), fn)(_f64(q), *extra, out)
+    return out
+
+
+def quat_log(q):
+    lib().tpo_quat_log.argtypes = [_dp, _dp]
+    return _q4("tpo_quat_log", q)
+
+
+def quat_exp(q):
+    lib().tpo_quat_exp.argtypes = [_dp, _dp]
+    return _q4("tpo_quat_exp", q)
+
+
+def quat_power(q, power):
+    lib().tpo_quat_power.argtypes = [_dp, C.c_double, _dp]
+    return _q4("tpo_quat_power", q, float(power))
+
+
+def bsplineq_eval_curve(knots, degree, points, u):
+    L = lib()
+    L.tpo_bsplineq_eval_curve.restype = C.c_int
+    L.tpo_bsplineq_eval_curve.argtypes = [_dp, C.c_int, C.c_int, _dp, C.c_double, _dp]
+    k, p = _f64(knots), _f64(points)
+    out = np.zeros(4)
+    rc = L.tpo_bsplineq_eval_curve(k, len(k), int(degree), p, float(u), out)
+    if rc != 0:
+        raise ValueError("parameter outside the knot range")
+    return out
+
+
+def sample_pose_spline(knots, translation_points, rotation_points, path_start, delta, N):
+    L = lib()
+    L.tpo_sample_pose_spline.restype = C.c_int
+    L.tpo_sample_pose_spline.argtypes = [_dp, C.c_int, _dp, _dp, C.c_int, C.c_double, C.c_double,
+                                         C.c_int, _dp]
+    k, t, r = _f64(knots), _f64(translation_points), _f64(rotation_points)
+    out = np.zeros((N, 7))
+    rc = L.tpo_sample_pose_spline(k, len(k), t, r, t.shape[0], float(path_start), float(delta), int(N), out)
+    if rc != 0:
+        raise ValueError("pose spline evaluation failed")
+    return out

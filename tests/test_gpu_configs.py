@@ -304,3 +304,37 @@ def test_pipelined_engine_gives_the_same_results_in_order(env):
     torch.cuda.synchronize()
     assert torch.equal(a["time"], ref["time"])
     E1.close(); E2.close()
+
+
+def test_pose_spline_sampling_matches_the_oracle(env):
+    """tpamd_sample_pose_splines_*: BSplineQ::EvalCurve (splines/bsplineq.cc:223-244) and the
+    translation spline for Cartesian batches. The basis and the translations are bit-equal to the
+    oracle; the quaternions go through log/atan2/sin/cos/exp of the device math library and are
+    held to 1e-12 (the reference's own IsApprox tolerance for this code, north star: 1e-6)."""
+    eng, syn, tpo = env["eng"], env["syn"], env["tpo"]
+    E = env["E"]
+    rng = np.random.default_rng(7)
+    B, W, N = 12, 6, 700
+    P = 3 * W - 2
+    knots = np.zeros((B, P + 3)); tr = np.zeros((B, P, 3)); rot = np.zeros((B, P, 4))
+    for b in range(B):
+        jb = syn.make_joint_batch(1, 3, N, num_waypoints=W, first_path_index=700 + b)
+        knots[b] = jb["knots"][0]
+        tr[b] = jb["control_points"][0]
+        q = rng.normal(size=(P, 4))
+        if b % 3 == 0:
+            q[5] = q[4]                                  # identical neighbours: |v| = 0 branch of QuatLog
+        if b % 4 == 1:
+            q[7] = -q[6]                                 # antipodal representation of the same rotation
+        rot[b] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    delta = knots[:, -1] / (N - 40)                      # the last samples run past the spline
+    start = np.where(np.arange(B) % 2 == 0, 0.0, 0.3 * delta)
+    poses = E.sample_pose_splines(knots, tr, rot, start, delta, N)
+    past_end = 0
+    for b in range(B):
+        ref = tpo.sample_pose_spline(knots[b], tr[b], rot[b], start[b], delta[b], N)
+        np.testing.assert_array_equal(poses[b, :, :3], ref[:, :3])
+        assert np.max(np.abs(poses[b, :, 3:] - ref[:, 3:])) <= 1e-12
+        assert np.max(np.abs(np.linalg.norm(poses[b, :, 3:], axis=1) - 1.0)) <= 1e-12
+        past_end += int((poses[b, :, :3] == tr[b, -1]).all(axis=1).sum())
+    assert past_end >= B * 30

@@ -27,6 +27,28 @@ def numbers(text):
     return [float(x) for x in re.findall(NUM, text)]
 
 
+def extract_quat_exp_tables():
+    """QuatExpAndLogTest.ResultsMatchGoldenValues (splines/bsplineq_test.cc:99-198): 15 random
+    quaternions (constructor order w, x, y, z) and Mathematica's Exp of them."""
+    src = open(os.path.join(REF, "splines", "bsplineq_test.cc")).read()
+    out = {}
+    for key, name in (("input", "golden_input"), ("exp", "golden_exp_output")):
+        m = re.search(r"%s\[kGoldenDataCount\]\s*=\s*\{(.*?)\};" % name, src, re.S)
+        assert m, name
+        vals = numbers(m.group(1))
+        assert len(vals) == 60, (name, len(vals))
+        out[key] = [vals[4 * i:4 * i + 4] for i in range(15)]
+    fixture = {
+        "source": "trajectory_planning/splines/bsplineq_test.cc:99-198 (Mathematica Exp[] of random quaternions)",
+        "order": "w, x, y, z",
+        "tolerance": "IsApprox: Eigen dummy_precision 1e-12 relative",
+        "input": out["input"], "exp": out["exp"],
+    }
+    with open(os.path.join(OUT, "quat_exp_golden.json"), "w") as f:
+        json.dump(fixture, f, indent=0)
+    print("quat_exp_golden.json: 15 quaternion pairs")
+
+
 def extract_bspline_tables():
     src = open(os.path.join(REF, "splines", "bspline_test.cc")).read()
     tables = {}
@@ -99,6 +121,7 @@ def extract_lp_regression():
 
 
 if __name__ == "__main__":
+    extract_quat_exp_tables()
     if not os.path.isdir(REF):
         sys.exit("reference tree not present; fixtures are already committed")
     os.makedirs(OUT, exist_ok=True)

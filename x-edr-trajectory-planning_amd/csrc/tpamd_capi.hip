@@ -880,6 +880,57 @@ int tpamd_sample_joint_paths_host(tpamd_engine *e, int num_paths, int num_dofs, 
   return 0;
 }
 
+int tpamd_sample_pose_splines_device(tpamd_engine *e, int num_paths, int num_samples, int num_points,
+                                     const double *knots, const double *translation_points,
+                                     const double *rotation_points, const double *path_start,
+                                     const double *delta, double *poses, void *hip_stream) {
+  if (!e || !knots || !translation_points || !rotation_points || !path_start || !delta || !poses)
+    return TPAMD_E_INVALID_ARGUMENT;
+  if (num_paths <= 0) return num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (num_samples < 1 || num_points < 3) return TPAMD_E_UNSUPPORTED;
+  const size_t lds = ((size_t)(num_points + 3) + 7 * (size_t)num_points) * 8;
+  if (lds > 64 * 1024) return TPAMD_E_UNSUPPORTED;
+  TPAMD_ON_DEVICE(e);
+  hipLaunchKernelGGL(k_sample_pose_splines, dim3((num_samples + 255) / 256, num_paths), dim3(256), lds,
+                     (hipStream_t)hip_stream, num_samples, num_points, knots, translation_points,
+                     rotation_points, path_start, delta, poses);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int tpamd_sample_pose_splines_host(tpamd_engine *e, int num_paths, int num_samples, int num_points,
+                                   const double *knots, const double *translation_points,
+                                   const double *rotation_points, const double *path_start,
+                                   const double *delta, double *poses) {
+  if (!e || !knots || !translation_points || !rotation_points || !path_start || !delta || !poses)
+    return TPAMD_E_INVALID_ARGUMENT;
+  if (num_paths <= 0) return num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = num_paths, N = num_samples, P = num_points;
+  TPAMD_ON_DEVICE(e);
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_k = s.take<double>(B * (P + 3)), *d_t = s.take<double>(B * P * 3), *d_r = s.take<double>(B * P * 4);
+    double *d_ps = s.take<double>(B), *d_dl = s.take<double>(B), *d_out = s.take<double>(B * N * 7);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    hipStream_t st = nullptr;
+    HIPCHK(hipMemcpyAsync(d_k, knots, B * (P + 3) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_t, translation_points, B * P * 3 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_r, rotation_points, B * P * 4 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ps, path_start, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_dl, delta, B * 8, hipMemcpyHostToDevice, st));
+    int rc = tpamd_sample_pose_splines_device(e, num_paths, num_samples, num_points, d_k, d_t, d_r, d_ps,
+                                              d_dl, d_out, st);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(poses, d_out, B * N * 7 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+  }
+  return 0;
+}
+
 int tpamd_optimize_rows_host(tpamd_engine *e, const tpamd_rows_batch *bt,
                              const tpamd_rows_inputs *in, const tpamd_path_outputs *out) {
   if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;

@@ -294,6 +294,139 @@ __global__ void k_sample_only(int N, int D, int P, const double *knots_g, const 
   }
 }
 
+
+// ------------------------------------------------------------ pose-spline sampling
+// The pose targets TimeableCartesianSplinePath::SamplePath evaluates before it calls the IK
+// callback (timeable_path_cartesian_spline.cc:484-503), for B paths at once: the translation
+// spline (degree-2 BSpline3d, BSplineT::EvalCurve splines/bspline.h:512-536) and the rotation
+// spline (degree-2 BSplineQ::EvalCurve splines/bsplineq.cc:223-244 with the cumulative basis
+// :309-317 and QuatPower = exp(p log q) :112-146) on a shared knot vector, at
+// parameter = path_start + i * delta; beyond knots.back() - delta the last control pose is
+// repeated (:488, :499-502). Quaternions are [w, x, y, z]; poses [B][N][7] = (t | q).
+// The operations follow the reference in order; log / atan2 / sin / cos / exp come
+// from the device math library, so results agree to rounding, not bit for bit.
+struct Quat { double w, x, y, z; };
+
+__device__ __forceinline__ Quat quat_mul(const Quat &a, const Quat &b) {
+  Quat r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  return r;
+}
+__device__ __forceinline__ double quat_sqnorm(const Quat &q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+__device__ __forceinline__ Quat quat_inverse(const Quat &q) {
+  const double n2 = quat_sqnorm(q);
+  Quat r = {0.0, 0.0, 0.0, 0.0};
+  if (n2 > 0.0) { r.w = q.w / n2; r.x = -q.x / n2; r.y = -q.y / n2; r.z = -q.z / n2; }
+  return r;
+}
+// bsplineq.cc:98-108
+__device__ __forceinline__ void quat_normalize_positive_real(Quat &q) {
+  if (q.w < 0) { q.w *= -1.0; q.x *= -1.0; q.y *= -1.0; q.z *= -1.0; }
+  if (fabs(quat_sqnorm(q) - 1.0) > 1e-12) {
+    const double n = sqrt(quat_sqnorm(q));
+    q.w /= n; q.x /= n; q.y /= n; q.z /= n;
+  }
+}
+// Eigen stableNorm / stableNormalized of the vector part (restated as in the oracle)
+__device__ __forceinline__ double vec3_stable_norm(double x, double y, double z) {
+  double mx = fabs(x);
+  if (fabs(y) > mx) mx = fabs(y);
+  if (fabs(z) > mx) mx = fabs(z);
+  if (!(mx > 0.0)) return mx;
+  const double inv = 1.0 / mx;
+  const double a = x * inv, b = y * inv, c = z * inv;
+  return mx * sqrt(a * a + b * b + c * c);
+}
+__device__ __forceinline__ void vec3_stable_normalized(double &x, double &y, double &z) {
+  double w = fabs(x);
+  if (fabs(y) > w) w = fabs(y);
+  if (fabs(z) > w) w = fabs(z);
+  const double a = x / w, b = y / w, c = z / w;
+  const double zz = a * a + b * b + c * c;
+  if (zz > 0.0) {
+    const double s = sqrt(zz);
+    x = a / s; y = b / s; z = c / s;
+  }
+}
+// bsplineq.cc:136-146 with QuatLog :112-125 and QuatExp :127-134
+__device__ __forceinline__ Quat quat_power(Quat q, double power) {
+  quat_normalize_positive_real(q);
+  Quat l;
+  {
+    const double nv = vec3_stable_norm(q.x, q.y, q.z);
+    l.w = 0.5 * log(quat_sqnorm(q));
+    if (nv > 1e-12) {
+      double nx = q.x, ny = q.y, nz = q.z;
+      vec3_stable_normalized(nx, ny, nz);
+      const double ang = atan2(nv, q.w);
+      l.x = nx * ang; l.y = ny * ang; l.z = nz * ang;
+    } else {
+      l.x = q.x; l.y = q.y; l.z = q.z;
+    }
+  }
+  l.w *= power; l.x *= power; l.y *= power; l.z *= power;
+  Quat r;
+  {
+    const double nv = vec3_stable_norm(l.x, l.y, l.z);
+    double nx = l.x, ny = l.y, nz = l.z;
+    r.w = cos(nv);
+    vec3_stable_normalized(nx, ny, nz);
+    const double sn = sin(nv);
+    r.x = nx * sn; r.y = ny * sn; r.z = nz * sn;
+    const double e = exp(l.w);
+    r.w *= e; r.x *= e; r.y *= e; r.z *= e;
+  }
+  return r;
+}
+
+// grid = (ceil(N/TPB), B); dynamic LDS: knots[P+3] | translation [P][3] | rotation [P][4]
+__global__ void k_sample_pose_splines(int N, int P, const double *knots_g, const double *trans_g,
+                                      const double *rot_g, const double *path_start,
+                                      const double *delta_g, double *poses) {
+  extern __shared__ double lds[];
+  const int TPB = blockDim.x, tid = threadIdx.x, b = blockIdx.y, K = P + 3;
+  double *s_knots = lds, *s_t = lds + K, *s_r = s_t + 3 * P;
+  for (int k = tid; k < K; k += TPB) s_knots[k] = knots_g[(size_t)b * K + k];
+  for (int k = tid; k < 3 * P; k += TPB) s_t[k] = trans_g[(size_t)b * 3 * P + k];
+  for (int k = tid; k < 4 * P; k += TPB) s_r[k] = rot_g[(size_t)b * 4 * P + k];
+  __syncthreads();
+  const int i = blockIdx.x * TPB + tid;
+  if (i >= N) return;
+  double *out = poses + ((size_t)b * N + i) * 7;
+  const double delta = delta_g[b];
+  const double kend = s_knots[K - 1];
+  const double parameter = path_start[b] + i * delta;
+  if (!(parameter < kend - delta) || parameter < s_knots[0]) {
+    // past the end: the last control pose (a parameter below the first knot is the caller's
+    // error in the reference; it gets the last pose here as well rather than garbage)
+    for (int d = 0; d < 3; d++) out[d] = s_t[3 * (P - 1) + d];
+    for (int d = 0; d < 4; d++) out[3 + d] = s_r[4 * (P - 1) + d];
+    return;
+  }
+  const int span = knot_span_deg2(s_knots, K, parameter);
+  double ders[3][3];
+  basis_ders_deg2(s_knots, span, parameter, ders);   // ders[0][*]: the basis of NURBS A2.2
+  const double b0 = ders[0][0], b1 = ders[0][1], b2 = ders[0][2];
+  const double *t0 = s_t + 3 * (span - 2);
+  for (int d = 0; d < 3; d++) {
+    double v = 0.0;
+    v += b0 * t0[d]; v += b1 * t0[3 + d]; v += b2 * t0[6 + d];
+    out[d] = v;
+  }
+  const double cum1 = b2, cum0 = cum1 + b1;          // bsplineq.cc:313-316
+  const double *r0 = s_r + 4 * (span - 2);
+  const Quat p0 = {r0[0], r0[1], r0[2], r0[3]}, p1 = {r0[4], r0[5], r0[6], r0[7]},
+             p2 = {r0[8], r0[9], r0[10], r0[11]};
+  Quat q = p0;
+  q = quat_mul(q, quat_power(quat_mul(quat_inverse(p0), p1), cum0));
+  q = quat_mul(q, quat_power(quat_mul(quat_inverse(p1), p2), cum1));
+  quat_normalize_positive_real(q);
+  out[3] = q.w; out[4] = q.x; out[5] = q.y; out[6] = q.z;
+}
+
 // ------------------------------------------- Cartesian paths: rows from IK output
 // One thread per (path, sample). ComputePathDerivatives
 // (timeable_path_cartesian_spline.cc:39-68): forward differences of the IK positions,

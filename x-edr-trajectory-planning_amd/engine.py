@@ -125,6 +125,7 @@ ABI_SYMBOLS = [
     "tpamd_time_joint_paths_host", "tpamd_sample_joint_paths_host",
     "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
     "tpamd_time_cartesian_paths_device", "tpamd_time_cartesian_paths_host",
+    "tpamd_sample_pose_splines_device", "tpamd_sample_pose_splines_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
     "tpamd_resample_uniform_host", "tpamd_resample_skip_device", "tpamd_resample_skip_host",
     "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
@@ -184,6 +185,10 @@ def load_library():
     L.tpamd_time_cartesian_paths_host.argtypes = [vp, C.POINTER(_CartesianBatch),
                                                   C.POINTER(_CartesianInputs),
                                                   C.POINTER(_PathOutputs)]
+    L.tpamd_sample_pose_splines_host.restype = i
+    L.tpamd_sample_pose_splines_host.argtypes = [vp, i, i, i] + [vp] * 6
+    L.tpamd_sample_pose_splines_device.restype = i
+    L.tpamd_sample_pose_splines_device.argtypes = [vp, i, i, i] + [vp] * 6 + [vp]
     L.tpamd_find_max_sd2_host.restype = i
     L.tpamd_find_max_sd2_host.argtypes = [vp, i, i] + [vp] * 7
     L.tpamd_query_device.restype = i
@@ -343,6 +348,22 @@ class Engine:
             _check(self._lib.tpamd_time_cartesian_paths_device(self._h, C.byref(bt), C.byref(ci),
                                                                C.byref(po), _stream_ptr(stream)),
                    "tpamd_time_cartesian_paths_device")
+
+    def sample_pose_splines(self, knots, translation_points, rotation_points, path_start, delta,
+                            num_samples):
+        """Host numpy arrays: knots [B][P+3], translation [B][P][3], rotation [B][P][4] (w, x, y,
+        z) -> poses [B][N][7] (tpamd_sample_pose_splines_host)."""
+        kn = np.ascontiguousarray(knots, dtype=np.float64)
+        tr = np.ascontiguousarray(translation_points, dtype=np.float64)
+        ro = np.ascontiguousarray(rotation_points, dtype=np.float64)
+        B, P, _ = tr.shape
+        ps = np.ascontiguousarray(np.broadcast_to(path_start, (B,)), dtype=np.float64)
+        dl = np.ascontiguousarray(np.broadcast_to(delta, (B,)), dtype=np.float64)
+        out = np.zeros((B, int(num_samples), 7))
+        _check(self._lib.tpamd_sample_pose_splines_host(self._h, B, int(num_samples), P, _ptr(kn),
+                                                        _ptr(tr), _ptr(ro), _ptr(ps), _ptr(dl),
+                                                        _ptr(out)), "tpamd_sample_pose_splines_host")
+        return out
 
     def find_max_sd2(self, a, b, lower, upper):
         """Host numpy [num][C] -> (sd2max, sddmax, sd2zero) [num]."""
