@@ -605,6 +605,78 @@ static void TestPlanAgainstOracle() {
   }
 }
 
+// SwitchToWaypointPath (timeable_path_joint_spline.cc:209-250) while a plan is being followed,
+// as in the reference's SwitchToNewJointWaypointPathWorks (path_timing_trajectory_test.cc:298-420):
+// plan, switch to a new waypoint path at a parameter ahead of the robot, carry the current
+// velocity over as the initial velocity, keep replanning to the end. The HIP-backed planner and
+// the oracle's Plan see the same edited spline (state kModifiedPath) and must agree bit for bit;
+// the trajectory must stay continuous across the switch and end at the new last waypoint.
+static void TestSwitchPathPlanning() {
+  using Method = PathTimingTrajectoryOptions::TimeSamplingMethod;
+  const int64_t kMs = 1000000;
+  const int D = 3, N = 1000;
+  auto V3 = [](double x, double y, double z) { VectorXd v(3); v[0] = x; v[1] = y; v[2] = z; return v; };
+  auto path = std::make_shared<TimeableJointSplinePath>(
+      JointPathOptions().set_num_dofs(D).set_num_path_samples(N).set_delta_parameter(0.001));
+  PathTimingTrajectory planner(PathTimingTrajectoryOptions().SetTimeStep(Milliseconds(4)).SetNumDofs(D)
+                                   .SetNumPathSamples(N).SetTimeSamplingMethod(Method::kUniformlyInTime));
+  CHECK(planner.SetPath(path).ok());
+  const std::vector<VectorXd> wps = {V3(1, 2, 3), V3(-1, -2, -3), V3(0.5, 1.0, 1.5)};
+  const std::vector<VectorXd> new_wps = {V3(1, 2, 3), V3(0.5, 1.0, 5.5)};
+  CHECK(path->SetWaypoints({wps.data(), wps.size()}).ok());
+  std::vector<double> vmax(D, 1.0), amax(D, 2.0);
+  CHECK(path->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+  CHECK(path->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+  tpo_planner *o = tpo_planner_create(D, N, 0.001, path->options().constraint_safety(), 4 * kMs, 0, 10000, 1e-3);
+  tpo_planner_set_limits(o, vmax.data(), amax.data());
+  tpo_planner_set_spline(o, path->knots().data(), (int)path->knots().size(), path->packed_control_points().data(),
+                         (int)path->num_control_points(), TPO_PATH_NEW);
+  int64_t start = 0;
+  for (int loop = 0; loop < 3; loop++) {      // follow the first path for a while
+    CHECK(planner.Plan(tpamd::compat::FromUnixNanos(start), Milliseconds(750)).ok());
+    CHECK(tpo_planner_plan(o, start, 750 * kMs) == TPO_PLAN_OK);
+    ComparePlannerWithOracle(planner, o, D);
+    start += 200 * kMs;
+  }
+  CHECK(!planner.IsTrajectoryAtEnd());
+  // the sample at the next start time: its velocity is carried over, the switch happens ahead of it
+  size_t k = 0;
+  while (k + 1 < planner.GetTime().size() && planner.GetTime()[k] < (double)start / 1e9 - 1e-9) k++;
+  const VectorXd v_now = planner.GetVelocities()[k];
+  const VectorXd q_now = planner.GetPositions()[k];
+  const double s_keep = planner.GetPathParameters()[std::min(k + 60, planner.GetPathParameters().size() - 1)];
+  CHECK(path->SwitchToWaypointPath(s_keep, {new_wps.data(), new_wps.size()}).ok());
+  CHECK(path->GetState() == TimeablePath::State::kModifiedPath);
+  CHECK(path->SetInitialVelocity({v_now.data(), v_now.size()}).ok());
+  tpo_planner_set_spline(o, path->knots().data(), (int)path->knots().size(), path->packed_control_points().data(),
+                         (int)path->num_control_points(), TPO_PATH_MODIFIED);
+  tpo_planner_set_initial_velocity(o, v_now.data());
+  int loops = 0;
+  bool first = true;
+  while (!planner.IsTrajectoryAtEnd() && loops < 100) {
+    const bool ok = planner.Plan(tpamd::compat::FromUnixNanos(start), Milliseconds(750)).ok();
+    const int rc = tpo_planner_plan(o, start, 750 * kMs);
+    CHECK(ok && rc == TPO_PLAN_OK);
+    if (!ok || rc != TPO_PLAN_OK) break;
+    ComparePlannerWithOracle(planner, o, D);
+    if (first) {                               // continuity across the switch
+      for (int d = 0; d < D; d++) {
+        CHECK(std::fabs(planner.GetPositions().front()[d] - q_now[d]) < 1e-6);
+        CHECK(std::fabs(planner.GetVelocities().front()[d] - v_now[d]) < 2e-3);
+      }
+      first = false;
+    }
+    start = std::min<int64_t>(tpo_planner_end_time(o), start + 200 * kMs);
+    loops++;
+  }
+  CHECK(planner.IsTrajectoryAtEnd() && loops > 1);
+  for (int d = 0; d < D; d++) {
+    CHECK(planner.GetVelocities().back()[d] == 0.0);
+    CHECK(std::fabs(planner.GetPositions().back()[d] - new_wps.back()[d]) < 1e-9);
+  }
+  tpo_planner_destroy(o);
+}
+
 int main() {
   TestProfileAgainstOracle();
   TestJointPathAndPlanner();
@@ -613,6 +685,7 @@ int main() {
   TestCartesianBatch();
   TestPlanBatch();
   TestPlanAgainstOracle();
+  TestSwitchPathPlanning();
   if (g_fail == 0) std::printf("ALL OK\n");
   else std::printf("%d CHECKS FAILED\n", g_fail);
   return g_fail == 0 ? 0 : 1;

@@ -48,6 +48,7 @@ inline Status FailedPreconditionError(std::string m) { return Status(StatusCode:
 inline Status NotFoundError(std::string m) { return Status(StatusCode::kNotFound, std::move(m)); }
 inline Status InternalError(std::string m) { return Status(StatusCode::kInternal, std::move(m)); }
 inline Status OutOfRangeError(std::string m) { return Status(StatusCode::kOutOfRange, std::move(m)); }
+inline Status UnimplementedError(std::string m) { return Status(StatusCode::kUnimplemented, std::move(m)); }
 inline Status DeadlineExceededError(std::string m) { return Status(StatusCode::kDeadlineExceeded, std::move(m)); }
 
 template <typename T>

@@ -379,7 +379,6 @@ void PathTimingTrajectory::EraseTrajectoryBefore(Time time) {
 // path_timing_trajectory.cc:579-630: everything before the window loop.
 Status PathTimingTrajectory::PlanPrologue(Time start, Duration time_horizon, bool *needs_windows) {
   *needs_windows = false;
-  const double start_sec = TimeToSec(start);
   if (path_ == nullptr) return FailedPreconditionError("No path set.");
   if (Status st = HandleTimeArguments(start); !st.ok()) return st;
   UpdatePathTrackingStatus();

@@ -224,6 +224,78 @@ bool TimeOptimalPathProfile::GetPreviousDiscreteValues(Scalar t, Scalar *sk, Sca
   return true;
 }
 
+namespace {
+constexpr double kTinyHost = 2.220446049250313e-16 * 1e5;   // time_optimal_path_timing.h:275-279
+constexpr double kMaxSd2Host = 1e6;
+bool IsTinyHost(double v) { return std::fabs(v) < kTinyHost; }
+
+// time_optimal_path_timing.cc:954-981
+bool Intersect(double A1, double B1, double e1, double A2, double B2, double e2, double *sdd, double *sp2) {
+  const double det = A1 * B2 - B1 * A2;
+  if (IsTinyHost(det)) {
+    if (IsTinyHost(A1)) {
+      *sdd = 0;
+      if (IsTinyHost(B1)) return false;
+      *sp2 = e1 / B1;
+      return true;
+    }
+    return false;
+  }
+  const double inv_det = 1.0 / det;
+  *sdd = (B2 * e1 - B1 * e2) * inv_det;
+  *sp2 = (-A2 * e1 + A1 * e2) * inv_det;
+  return true;
+}
+
+// time_optimal_path_timing.cc:1526-1538
+bool RowsValid(const TimeOptimalPathProfile::Constraint &c, double sdd, double sd2) {
+  for (int i = 0; i < c.size(); i++) {
+    const double tmp = c.a_coefficient(i) * sdd + c.b_coefficient(i) * sd2;
+    if (tmp + kTinyHost < c.lower(i)) return false;
+    if (tmp - kTinyHost > c.upper(i)) return false;
+  }
+  return true;
+}
+}  // namespace
+
+void TimeOptimalPathProfile::FindMaxSd2BruteForce(const Constraint &constr, Scalar *sd2max, Scalar *sddmax,
+                                                  Scalar *sd2zero) const {
+  const int C = constr.size();
+  *sd2max = 0;
+  *sddmax = 0;
+  *sd2zero = kMaxSd2Host;
+  for (int c = 0; c < C; c++) {
+    if (constr.b_coefficient(c) > kTinyHost) {
+      const Scalar tmp = constr.upper(c) / constr.b_coefficient(c);
+      if (tmp < *sd2zero) *sd2zero = tmp;
+    } else if (constr.b_coefficient(c) < -kTinyHost) {
+      const Scalar tmp = constr.lower(c) / constr.b_coefficient(c);
+      if (tmp < *sd2zero) *sd2zero = tmp;
+    }
+  }
+  for (int c1 = 0; c1 < C; c1++) {
+    for (int c2 = c1 + 1; c2 < C; c2++) {
+      for (int which = 0; which < 4; which++) {     // upper/upper, upper/lower, lower/upper, lower/lower
+        const Scalar e1 = (which < 2) ? constr.upper(c1) : constr.lower(c1);
+        const Scalar e2 = (which % 2 == 0) ? constr.upper(c2) : constr.lower(c2);
+        Scalar sd2, sdd;
+        if (Intersect(constr.a_coefficient(c1), constr.b_coefficient(c1), e1, constr.a_coefficient(c2),
+                      constr.b_coefficient(c2), e2, &sdd, &sd2)) {
+          if ((sd2 > *sd2max) && RowsValid(constr, sdd, sd2)) {
+            *sd2max = sd2;
+            *sddmax = sdd;
+          }
+        }
+      }
+    }
+  }
+  if (0 == *sd2max || *sd2max > kMaxSd2Host) {
+    *sd2max = kMaxSd2Host;
+    *sddmax = 0;
+  }
+  if (0 == *sd2zero) *sd2zero = kMaxSd2Host;
+}
+
 void TimeOptimalPathProfile::FindMaxSd2Simplex(const Constraint &constr, Scalar *sd2max,
                                                Scalar *sddmax, Scalar *sd2zero) {
   tpamd_engine *engine = ::tpamd::shared_engine();

@@ -81,6 +81,12 @@ class TimeOptimalPathProfile {
                                  Scalar *tk) const;
   int GetPreviousIndex(Scalar t) const;
   Scalar GetMaxTimeIncrement() const;
+  // The reference's cross-check of the LP (time_optimal_path_timing.cc:1010-1103, public "for
+  // testability" at .h:198-201; its only callers are tests): every pairwise intersection of
+  // row bounds, validated against all rows. O(C^3) for one sample on the host -- a checking
+  // tool next to the GPU LP below, never on the solve path.
+  void FindMaxSd2BruteForce(const Constraint &constr, Scalar *sd2max, Scalar *sddmax,
+                            Scalar *sd2zero) const;
   // One LP on the GPU (FindMaxSd2Simplex, time_optimal_path_timing.cc:1149-1363).
   void FindMaxSd2Simplex(const Constraint &constr, Scalar *sd2max, Scalar *sddmax,
                          Scalar *sd2zero);

@@ -5,6 +5,7 @@
 #include <limits>
 
 #include "engine_handle.h"
+#include "spline_edit.h"
 
 namespace trajectory_planning {
 
@@ -96,25 +97,37 @@ Status TimeableJointSplinePath::SetWaypoints(Span<const VectorXd> waypoints) {
 // Waypoints -> 3W-2 control points with rounded corners (splines/spline_utils.cc:47-102),
 // uniform degree-2 knots by running accumulation (splines/bspline_base.cc:356-381),
 // scaled by the control polygon length (timeable_path_joint_spline.cc:252-292).
+void TimeableJointSplinePath::PolyLineToControlPoints(const std::vector<VectorXd> &waypoints, double radius,
+                                                      std::vector<VectorXd> *control_points) {
+  const size_t W = waypoints.size();
+  auto &cp = *control_points;
+  if (W == 1) {
+    cp.assign(4, waypoints.front());
+    return;
+  }
+  cp.assign(3 * W - 2, VectorXd(waypoints.front().size()));
+  for (size_t i = 0; i < W; i++) cp[3 * i] = waypoints[i];
+  for (size_t i = 1; i + 1 < W; i++) {
+    const size_t k = 3 * i;
+    cp[k + 1] = Plus(cp[k], CornerOffset(cp[k], cp[k + 3], radius));
+    cp[k - 1] = Plus(cp[k], CornerOffset(cp[k], cp[k - 3], radius));
+  }
+  cp[1] = Plus(cp[0], CornerOffset(cp[0], cp[3], radius));
+  const size_t sz = cp.size();
+  cp[sz - 2] = Plus(cp[sz - 1], CornerOffset(cp[sz - 1], cp[sz - 4], radius));
+}
+
+void TimeableJointSplinePath::PackControlPoints() {
+  const size_t P = control_points_.size(), D = options_.num_dofs();
+  packed_control_points_.resize(P * D);
+  for (size_t i = 0; i < P; i++)
+    for (size_t d = 0; d < D; d++) packed_control_points_[i * D + d] = control_points_[i][d];
+}
+
 Status TimeableJointSplinePath::FitSplineToWaypoints() {
   if (waypoints_.empty()) return InvalidArgumentError("Control point vector empty.");
-  const size_t W = waypoints_.size(), D = options_.num_dofs();
-  const double radius = options_.rounding();
-  if (W == 1) {
-    control_points_.assign(4, waypoints_.front());
-  } else {
-    control_points_.assign(3 * W - 2, VectorXd(D));
-    for (size_t i = 0; i < W; i++) control_points_[3 * i] = waypoints_[i];
-    auto &cp = control_points_;
-    for (size_t i = 1; i + 1 < W; i++) {
-      const size_t k = 3 * i;
-      cp[k + 1] = Plus(cp[k], CornerOffset(cp[k], cp[k + 3], radius));
-      cp[k - 1] = Plus(cp[k], CornerOffset(cp[k], cp[k - 3], radius));
-    }
-    cp[1] = Plus(cp[0], CornerOffset(cp[0], cp[3], radius));
-    const size_t sz = cp.size();
-    cp[sz - 2] = Plus(cp[sz - 1], CornerOffset(cp[sz - 1], cp[sz - 4], radius));
-  }
+  const size_t D = options_.num_dofs();
+  PolyLineToControlPoints(waypoints_, options_.rounding(), &control_points_);
   const size_t P = control_points_.size();
   const size_t nk = P + kSplineOrder + 1;
   knots_.assign(nk, 0.0);
@@ -129,9 +142,47 @@ Status TimeableJointSplinePath::FitSplineToWaypoints() {
   }
   const double weighted = std::max(length * 1.0, 0.1);
   for (double &k : knots_) k *= weighted;
-  packed_control_points_.resize(P * D);
-  for (size_t i = 0; i < P; i++)
-    for (size_t d = 0; d < D; d++) packed_control_points_[i * D + d] = control_points_[i][d];
+  PackControlPoints();
+  return OkStatus();
+}
+
+// timeable_path_joint_spline.cc:209-250
+Status TimeableJointSplinePath::SwitchToWaypointPath(const double keep_path_until,
+                                                     Span<const VectorXd> waypoints) {
+  for (const auto &wp : waypoints)
+    if (wp.size() != options_.num_dofs()) return InvalidArgumentError("waypoint has the wrong dimension");
+  if (knots_.empty()) return ::tpamd::compat::FailedPreconditionError("No path to switch from.");
+  path_state_ = State::kModifiedPath;
+  // the reference allocates twice the initial knot count, at least 100 (:262-268)
+  const int capacity = std::max<int>(2 * (int)knots_.size() + 3 * (int)waypoints.size() + 8, 100);
+  EditableBSpline spline;
+  if (Status st = spline.Init(kSplineOrder, capacity, {knots_.data(), knots_.size()},
+                              {control_points_.data(), control_points_.size()});
+      !st.ok())
+    return st;
+  if (Status st = spline.TruncateSplineAt(keep_path_until); !st.ok()) return st;
+  VectorXd switch_position(NumDofs());
+  if (Status st = spline.EvalCurve(keep_path_until, &switch_position); !st.ok()) return st;
+  const auto projection = ProjectPointOnPath(waypoints, switch_position);
+  if (!projection.ok()) return projection.status();
+  std::vector<VectorXd> new_waypoints;
+  new_waypoints.reserve(waypoints.size() + 1);
+  // the projected point becomes the first waypoint unless it coincides with the switch position
+  constexpr double kEpsilon = 1e-3;
+  double inf_norm = 0.0;
+  for (size_t d = 0; d < NumDofs(); d++)
+    inf_norm = std::max(inf_norm, std::fabs(switch_position[d] - (*projection).projected_point[d]));
+  if (inf_norm > kEpsilon) new_waypoints.push_back((*projection).projected_point);
+  const int first_waypoint = (*projection).line_parameter >= 0 ? (*projection).waypoint_index + 1
+                                                               : (*projection).waypoint_index;
+  for (size_t i = (size_t)first_waypoint; i < waypoints.size(); i++) new_waypoints.push_back(waypoints[i]);
+  if (new_waypoints.empty()) return InvalidArgumentError("No waypoints left after the switch position.");
+  std::vector<VectorXd> extra;
+  PolyLineToControlPoints(new_waypoints, options_.rounding(), &extra);
+  if (Status st = spline.ExtendWithControlPoints({extra.data(), extra.size()}); !st.ok()) return st;
+  knots_ = spline.knots();
+  control_points_ = spline.control_points();
+  PackControlPoints();
   return OkStatus();
 }
 

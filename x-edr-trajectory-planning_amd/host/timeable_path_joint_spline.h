@@ -19,6 +19,11 @@ class TimeableJointSplinePath : public TimeablePath {
   explicit TimeableJointSplinePath(const JointPathOptions &options);
 
   Status SetWaypoints(Span<const VectorXd> waypoints);
+  // timeable_path_joint_spline.h:40-47 / .cc:209-250: keep the path up to `keep_path_until`,
+  // then continue along `waypoints` (the spline is truncated there and extended with the new
+  // rounded control polygon; the state becomes kModifiedPath). Host-side edit: the next
+  // SamplePath / Plan / batch call picks up the new knots and control points.
+  Status SwitchToWaypointPath(double keep_path_until, Span<const VectorXd> waypoints);
 
   Status SetMaxJointVelocity(Span<const double> max_velocity) override;
   Status SetMaxJointAcceleration(Span<const double> max_acceleration) override;
@@ -62,6 +67,9 @@ class TimeableJointSplinePath : public TimeablePath {
 
  private:
   Status FitSplineToWaypoints();
+  static void PolyLineToControlPoints(const std::vector<VectorXd> &waypoints, double radius,
+                                      std::vector<VectorXd> *control_points);
+  void PackControlPoints();
 
   static constexpr int kSplineOrder = 2;
   const JointPathOptions options_;
