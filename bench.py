@@ -201,9 +201,12 @@ def main():
     ap.add_argument("--samples", type=int, default=2000)
     ap.add_argument("--gather", choices=("profile", "full"), default="profile",
                     help="multi-GPU payload: the timing profile (t, sd, sdd), or q as well")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="keep the sampling/LP kernel of step k+1 behind the sweep of step k "
-                         "(default: the engine overlaps them, tpamd_engine_set_pipelining)")
+    ap.add_argument("--pipeline", type=int, choices=(0, 1, 2), default=1,
+                    help="engine pipelining across steps (tpamd_engine_set_pipelining): 0 one kernel "
+                         "at a time; 1 (default) the sampling/LP kernel of step k+1 runs under the sweep of "
+                         "step k; 2 the sweep of step k+1 may also start while the slowest "
+                         "paths of step k are still running")
+    ap.add_argument("--no-pipeline", action="store_true", help="same as --pipeline 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -252,8 +255,9 @@ def main():
     # Steps are independent batches whose inputs are resident before the timed region starts, so
     # the engine may run the front stage of step k+1 (sampling + LP) under the sweep of step k;
     # every step still runs every kernel, and the timed region ends when the last step is done.
-    pipelined = not args.no_pipeline
-    E.set_pipelining(pipelined)
+    mode = 0 if args.no_pipeline else args.pipeline
+    pipelined = mode != 0
+    E.set_pipelining(mode)
     E.reserve(B, N, 2 * D)
     inp = eng.upload_joint_batch(batch, dev)
     # Gather payload, packed so that the multi-GPU collection is ONE gather per batch:
@@ -279,13 +283,30 @@ def main():
     def step():
         k = counter[0]
         counter[0] += 1
-        G.buffer(k)                       # the gather that last read this buffer is done
+        # the gather that last read this buffer is done (host-side too when the engine's own stream
+        # is about to write q into the payload)
+        G.buffer(k, host_sync=(pipelined and distributed and args.gather == "full"))
         E.time_joint_paths(inp, outs[k % 2], N)
-        G.launch(k)
+        if mode == 2:
+            # this stream is now ordered behind the PREVIOUS solve: its gather can go
+            if k >= 1 and k - 1 >= first[0]:
+                G.launch(k - 1)
+        else:
+            G.launch(k)
+
+    first = [0]
+
+    def finish():
+        """Everything issued so far is complete on this stream and gathered."""
+        if mode == 2 and counter[0] > first[0]:
+            E.fence()
+            G.launch(counter[0] - 1)
+        G.drain()
+        first[0] = counter[0]
 
     for _ in range(args.warmup):
         step()
-    G.drain()
+    finish()
     torch.cuda.synchronize()
 
     timing = not args.no_kernel_timing
@@ -297,7 +318,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    G.drain()                             # every batch's gather has landed on rank 0
+    finish()                              # every batch is solved and its gather has landed on rank 0
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -356,9 +377,12 @@ def main():
                                    "resident in HBM" % (what, B, D, N, P),
                        "paths_per_gpu": B, "total_paths": total_paths, "num_dofs": D,
                        "num_samples": N, "solved_paths": solved,
-                       "pipelined": ("sampling/LP kernel of step k+1 overlaps the sweep of step k "
-                                     "(two engine workspaces, second HIP stream)" if pipelined
-                                     else "no: one kernel at a time"),
+                       "pipelined": {0: "no: one kernel at a time",
+                                     1: "mode 1: the sampling/LP kernel of step k+1 runs under the sweep "
+                                        "of step k (two engine workspaces, one engine stream)",
+                                     2: "mode 2: as mode 1, and the sweep of step k+1 may start while the "
+                                        "slowest paths of step k are still running (sweeps on two engine "
+                                        "streams; all K steps complete inside the timed region)"}[mode],
                        "gather": {"mode": args.gather if distributed else "none (single GPU)",
                                   "bytes_per_path": gb,
                                   "bytes_into_rank0_per_step": gb * B * (world - 1),

@@ -64,15 +64,24 @@ const char *tpamd_error_string(int code);
 /* Pre-size the workspace for batches up to (num_paths, num_samples, num_rows). */
 int tpamd_engine_reserve(tpamd_engine *engine, int num_paths, int num_samples,
                          int num_rows);
-/* Pipelined mode for streams of joint-space solves (tpamd_time_joint_paths_device): the engine
- * keeps two workspaces and runs the front stage of a solve (set-up and the sampling / LP kernel,
- * which also writes out->q) on a stream of its own, so that it overlaps the extremal sweep of
- * the PREVIOUS solve; the sweep and every other output stay on the caller's stream, in order.
- * Contract while it is on: the inputs of a call (and its out->q buffer) must be ready when the
- * call is made -- the front stage is NOT ordered behind earlier work on the caller's stream --
- * and must stay untouched until the caller's stream has passed the call. Calls captured into a
- * HIP graph run unpipelined. Off by default; switching it off waits for the engine's stream. */
-int tpamd_engine_set_pipelining(tpamd_engine *engine, int on);
+/* Pipelined modes for streams of joint-space solves (tpamd_time_joint_paths_device). The engine
+ * keeps two workspaces, used alternately.
+ *   1: the front stage of a solve (set-up and the sampling / LP kernel, which also writes out->q)
+ *      runs on a stream of the engine, so that it overlaps the extremal sweep of the PREVIOUS
+ *      solve; the sweep and every other output stay on the caller's stream, in order.
+ *   2: the sweep runs on one of two engine streams as well, ordered behind the call's position in
+ *      the caller's stream and behind its own front stage, so that it can start while the slowest
+ *      paths of the previous solve are still running. The caller's stream is ordered behind the
+ *      PREVIOUS solve when a call returns; tpamd_engine_fence orders it behind all of them.
+ * Contract while a mode is on: the inputs of a call (and its out->q buffer) must be ready when the
+ * call is made -- the front stage is NOT ordered behind earlier work on the caller's stream -- and
+ * must stay untouched until the caller's stream has passed the call (mode 2: the fence). Calls
+ * captured into a HIP graph run unpipelined. 0 = off (default); changing the mode waits for the
+ * engine's streams. */
+int tpamd_engine_set_pipelining(tpamd_engine *engine, int mode);
+/* Make hip_stream wait for every solve issued so far (needed in mode 2 before the outputs of the
+ * last solve are used; harmless otherwise). */
+int tpamd_engine_fence(tpamd_engine *engine, void *hip_stream);
 /* Bytes of device workspace currently held. */
 size_t tpamd_engine_workspace_bytes(const tpamd_engine *engine);
 

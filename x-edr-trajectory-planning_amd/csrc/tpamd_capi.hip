@@ -72,9 +72,11 @@ struct tpamd_engine {
   // Pipelined mode (tpamd_engine_set_pipelining): two workspaces used alternately, the front
   // stage (set-up + sampling/LP kernel) of a joint-space solve runs on the engine's own stream
   // so that it overlaps the sweep of the previous solve.
-  bool pipelining = false;
+  int pipelining = 0;          // 0 off, 1 front stage on the engine's stream, 2 sweeps as well
   hipStream_t aux = nullptr;
-  hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_sweep[2] = {nullptr, nullptr};
+  hipStream_t sweep_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_front[2] = {nullptr, nullptr}, ev_sweep[2] = {nullptr, nullptr},
+             ev_call[2] = {nullptr, nullptr};
   void *slot_base[2] = {nullptr, nullptr};   // ws_base / ws_bytes of the slot not in use
   size_t slot_bytes[2] = {0, 0};
   int slot = 0;                // workspace slot e->ws_base currently refers to
@@ -464,6 +466,8 @@ void tpamd_engine_destroy(tpamd_engine *e) {
   for (int k = 0; k < 2; k++) {
     if (e->ev_front[k]) (void)hipEventDestroy(e->ev_front[k]);
     if (e->ev_sweep[k]) (void)hipEventDestroy(e->ev_sweep[k]);
+    if (e->ev_call[k]) (void)hipEventDestroy(e->ev_call[k]);
+    if (e->sweep_stream[k]) (void)hipStreamDestroy(e->sweep_stream[k]);
   }
   if (e->aux) (void)hipStreamDestroy(e->aux);
   if (e->stage_base) (void)hipFree(e->stage_base);
@@ -502,7 +506,7 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   // stage goes to the engine's stream, ordered only behind the sweep that last used this
   // workspace -- not behind the caller's stream (see tpamd_engine_set_pipelining). A stream that
   // is being captured into a graph cannot fork into the engine's stream: plain order then.
-  bool piped = e->pipelining;
+  bool piped = e->pipelining != 0;
   if (piped) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) piped = false;
@@ -550,8 +554,19 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
     else TPAMD_K1(0);
 #undef TPAMD_K1
   }
+  // Mode 2: the sweep goes to one of two engine streams as well, so that it can start while the
+  // previous solve's slowest paths are still running; it is ordered behind this call's position
+  // in the caller's stream (the output buffers are free) and behind its own front stage. The
+  // caller's stream is made to wait for the PREVIOUS solve only (tpamd_engine_fence for the rest).
+  const bool deferred = piped && e->pipelining == 2;
+  hipStream_t caller = st;
   if (piped) {
     HIPCHK(hipEventRecord(e->ev_front[slot], fs));
+    if (deferred) {
+      HIPCHK(hipEventRecord(e->ev_call[slot], caller));
+      st = e->sweep_stream[slot];
+      HIPCHK(hipStreamWaitEvent(st, e->ev_call[slot], 0));
+    }
     HIPCHK(hipStreamWaitEvent(st, e->ev_front[slot], 0));
   }
   JointSource src;
@@ -567,12 +582,21 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
                        out->qd, out->qdd);
   }
   if (piped) HIPCHK(hipEventRecord(e->ev_sweep[slot], st));
+  if (deferred) HIPCHK(hipStreamWaitEvent(caller, e->ev_sweep[1 - slot], 0));
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-int tpamd_engine_set_pipelining(tpamd_engine *e, int on) {
+int tpamd_engine_fence(tpamd_engine *e, void *hip_stream) {
   if (!e) return TPAMD_E_INVALID_ARGUMENT;
+  if (!e->aux) return 0;
+  TPAMD_ON_DEVICE(e);
+  for (int k = 0; k < 2; k++) HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, e->ev_sweep[k], 0));
+  return 0;
+}
+
+int tpamd_engine_set_pipelining(tpamd_engine *e, int on) {
+  if (!e || on < 0 || on > 2) return TPAMD_E_INVALID_ARGUMENT;
   TPAMD_ON_DEVICE(e);
   if (on && !e->aux) {
     // lowest priority: the front stage of the NEXT solve fills what the running sweep leaves
@@ -587,10 +611,15 @@ int tpamd_engine_set_pipelining(tpamd_engine *e, int on) {
     for (int k = 0; k < 2; k++) {
       HIPCHK(hipEventCreateWithFlags(&e->ev_front[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&e->ev_sweep[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&e->ev_call[k], hipEventDisableTiming));
+      HIPCHK(hipStreamCreateWithFlags(&e->sweep_stream[k], hipStreamNonBlocking));
     }
   }
-  if (!on && e->pipelining) HIPCHK(hipStreamSynchronize(e->aux));
-  e->pipelining = on != 0;
+  if (e->pipelining && on != e->pipelining) {   // leave the old mode with nothing in flight
+    HIPCHK(hipStreamSynchronize(e->aux));
+    for (int k = 0; k < 2; k++) HIPCHK(hipStreamSynchronize(e->sweep_stream[k]));
+  }
+  e->pipelining = on;
   return 0;
 }
 

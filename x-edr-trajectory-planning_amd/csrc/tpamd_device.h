@@ -248,6 +248,89 @@ __device__ __forceinline__ void find_sdd_both_joint_fixed(const double (&a)[D], 
   *sdd_min = smin;
 }
 
+// find_sdd_both_joint_fixed with a cheap screen in front of the exact work. A candidate
+// sdd_i = (+-hi_i - b_i sd2) / a_i is admissible iff it lies in every row's interval
+//   [(-hi_j - kTiny - b_j sd2) / a_j, (hi_j + kTiny - b_j sd2) / a_j]   (ends swapped for a_j < 0),
+// i.e. in their intersection [Lmax, Umin]. The interval ends are formed with the hardware
+// reciprocal estimate (the candidates themselves are among those ends), and only candidates
+// inside the intersection widened by 1e-6 relative -- typically the two constraints that are
+// active at the LP vertex -- go through the reference's operations: IEEE division, the row
+// checks in the reference's arithmetic, max/min of the admissible ones. A candidate outside the
+// widened intersection violates some row by far more than any rounding of the exact check, so
+// the reference rejects it as well; NaN estimates are never screened out. The survivors are
+// taken from the thread's LDS columns Q1/Q2 (dynamic row index per lane); the row checks use
+// the register copies. Same result as find_sdd_both_joint_fixed, bit for bit.
+template <int D>
+__device__ __forceinline__ void find_sdd_both_joint_screened(const double (&a)[D], const double (&b)[D],
+                                                             const double *Q1, const double *Q2, int stride,
+                                                             const double *lim_hi, double sd2,
+                                                             double *sdd_max, double *sdd_min) {
+  double smax = -DBL_MAX, smin = DBL_MAX;
+  bool vel_ok = true;
+#pragma unroll
+  for (int j = 0; j < D; j++) {
+    const double v = (a[j] * a[j]) * sd2;
+    if (v + kTiny < 0.0 || v - kTiny > lim_hi[D + j]) vel_ok = false;
+  }
+  if (vel_ok) {
+    double bs[D], hi[D], c_lo[D], c_hi[D];
+    double Lmax = -DBL_MAX, Umin = DBL_MAX;
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+      bs[j] = b[j] * sd2;
+      hi[j] = lim_hi[j];
+      const double r = __builtin_amdgcn_rcp(a[j]);
+      c_lo[j] = (-hi[j] - bs[j]) * r;          // estimate of the candidate on the lower bound
+      c_hi[j] = (hi[j] - bs[j]) * r;           // ... on the upper bound
+      if (!is_tiny(a[j])) {
+        const double pad = kTiny * fabs(r);
+        const double l = fmin(c_lo[j], c_hi[j]) - pad, u = fmax(c_lo[j], c_hi[j]) + pad;
+        // NaN ends (overflowing estimates) leave the intersection unchanged: never screens
+        if (l > Lmax) Lmax = l;
+        if (u < Umin) Umin = u;
+      }
+    }
+    unsigned survivors = 0;
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      if (!is_tiny(a[i])) {
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+          const double c = w ? c_hi[i] : c_lo[i];
+          const double mg = 1e-6 * (fabs(Lmax) + fabs(Umin) + fabs(c)) + 1e-290;
+          const bool out = (c < Lmax - mg) || (c > Umin + mg);
+          if (!out) survivors |= 1u << (2 * i + w);
+        }
+      }
+    }
+    while (__any(survivors != 0u)) {
+      const bool live = survivors != 0u;
+      const int slot = live ? (__ffs((int)survivors) - 1) : 0;
+      survivors &= survivors - 1u;
+      const int i = slot >> 1;
+      const double A = Q1[i * stride];
+      const double lim = (slot & 1) ? lim_hi[i] : -lim_hi[i];
+      const double sddi = (lim - Q2[i * stride] * sd2) / A;
+      if (live && (fabs(sddi) <= DBL_MAX) && ((sddi > smax) || (sddi < smin))) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < D; j++) {
+          const double v = a[j] * sddi + bs[j];
+          bad = bad | (fabs(v) - kTiny > hi[j]);
+        }
+        if (!bad) {
+          if (sddi > smax) smax = sddi;
+          if (sddi < smin) smin = sddi;
+        }
+      }
+    }
+  }
+  if (smax == -DBL_MAX) smax = 0;
+  if (smin == DBL_MAX) smin = 0;
+  *sdd_max = smax;
+  *sdd_min = smin;
+}
+
 // ---------------------------------------------------------------------------
 // 2-variable LP: FindMaxSd2Simplex, time_optimal_path_timing.cc:1149-1363, with
 // IsOptimal :1105-1147. The reference's constraint_set_ / active_set_ vectors

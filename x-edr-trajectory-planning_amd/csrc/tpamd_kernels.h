@@ -244,7 +244,7 @@ __global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
     double sd2max, sddmax, sd2zero, x0, y0;
     lp_find_max_sd2<WORDS, LdsRowsJoint, DT, 2 * DT>(r, C, &sd2max, &sddmax, &sd2zero, /*b_only_from=*/D,
                                                      q1r, q2r);
-    find_sdd_both_joint_fixed<(DT ? DT : 1)>(q1r, q2r, s_hi, sd2max, &x0, &y0);
+    find_sdd_both_joint_screened<(DT ? DT : 1)>(q1r, q2r, Q1, Q2, TPB, s_hi, sd2max, &x0, &y0);
     ws.m0[o] = sd2max;
     ws.z0[o] = sd2zero;
     ws.X0[o] = x0;
@@ -585,7 +585,7 @@ __global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Work
     const double vt = bt * sd2max, vr = br * sd2max;
     const bool ok = !(vt + kTiny < s_lo[2 * D] || vt - kTiny > s_hi[2 * D]) &&
                     !(vr + kTiny < s_lo[2 * D + 1] || vr - kTiny > s_hi[2 * D + 1]);
-    if (ok) find_sdd_both_joint_fixed<D>(q1r, q2r, s_hi, sd2max, &x0, &y0);
+    if (ok) find_sdd_both_joint_screened<D>(q1r, q2r, Q1, Q2, TPB, s_hi, sd2max, &x0, &y0);
   }
   ws.m0[o] = sd2max;
   ws.z0[o] = sd2zero;

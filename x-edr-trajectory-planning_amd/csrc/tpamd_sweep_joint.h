@@ -1217,8 +1217,15 @@ __host__ __device__ inline size_t sweep_joint_lds_bytes(int N) {
 // are data-independent after the backward extremal's first step, see add_extremal). Both
 // waves keep identical copies of the loop scalars. qd/qdd are written by the extremals as
 // the backward wave finishes with its share (emit_range); the tail is shared by the two waves.
+// TPAMD_SWEEP_WAVES_PER_EU (build-time, A/B): ask the compiler for a register budget that lets
+// that many waves share a SIMD (3 -> 168 VGPRs).
+#ifdef TPAMD_SWEEP_WAVES_PER_EU
+#define TPAMD_SWEEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TPAMD_SWEEP_WAVES_PER_EU, TPAMD_SWEEP_WAVES_PER_EU)))
+#else
+#define TPAMD_SWEEP_OCCUPANCY
+#endif
 template <int D, int E = 0>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128) TPAMD_SWEEP_OCCUPANCY
 k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
               double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
               int32_t *status_out, double *qd_out, double *qdd_out) {

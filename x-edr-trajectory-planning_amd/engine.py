@@ -120,7 +120,8 @@ _LIB = None
 # every symbol include/tpamd.h declares
 ABI_SYMBOLS = [
     "tpamd_engine_create", "tpamd_engine_destroy", "tpamd_version", "tpamd_error_string",
-    "tpamd_engine_reserve", "tpamd_engine_set_pipelining", "tpamd_engine_workspace_bytes",
+    "tpamd_engine_reserve", "tpamd_engine_set_pipelining", "tpamd_engine_fence",
+    "tpamd_engine_workspace_bytes",
     "tpamd_time_joint_paths_device",
     "tpamd_time_joint_paths_host", "tpamd_sample_joint_paths_host",
     "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
@@ -160,6 +161,8 @@ def load_library():
     L.tpamd_engine_reserve.argtypes = [vp, i, i, i]
     L.tpamd_engine_set_pipelining.restype = i
     L.tpamd_engine_set_pipelining.argtypes = [vp, i]
+    L.tpamd_engine_fence.restype = i
+    L.tpamd_engine_fence.argtypes = [vp, vp]
     L.tpamd_engine_workspace_bytes.restype = C.c_size_t
     L.tpamd_engine_workspace_bytes.argtypes = [vp]
     L.tpamd_time_joint_paths_device.restype = i
@@ -259,11 +262,16 @@ class Engine:
         _check(self._lib.tpamd_engine_reserve(self._h, num_paths, num_samples, num_rows),
                "tpamd_engine_reserve")
 
-    def set_pipelining(self, on=True):
-        """Overlap the sampling/LP kernel of a joint solve with the previous solve's sweep
-        (include/tpamd.h tpamd_engine_set_pipelining: inputs must be ready at call time)."""
-        _check(self._lib.tpamd_engine_set_pipelining(self._h, 1 if on else 0),
+    def set_pipelining(self, mode=1):
+        """0 off; 1: the sampling/LP kernel of a joint solve overlaps the previous solve's sweep;
+        2: sweeps of consecutive solves overlap as well, outputs ordered by the next call or
+        fence() (include/tpamd.h tpamd_engine_set_pipelining: inputs must be ready at call time)."""
+        _check(self._lib.tpamd_engine_set_pipelining(self._h, int(mode)),
                "tpamd_engine_set_pipelining")
+
+    def fence(self, stream=None):
+        """Order `stream` (default: torch's current stream) behind every solve issued so far."""
+        _check(self._lib.tpamd_engine_fence(self._h, _stream_ptr(stream)), "tpamd_engine_fence")
 
     @property
     def workspace_bytes(self):

@@ -82,11 +82,16 @@ class PipelinedGather:
                          for _ in range(depth)]
         self.work = [None] * depth
 
-    def buffer(self, k):
+    def buffer(self, k, host_sync=False):
+        """host_sync: also block the HOST until the gather that last read this buffer is done.
+        Needed when the next writer is not ordered on the current stream -- the engine's pipelined
+        mode writes q from its own stream (include/tpamd.h tpamd_engine_set_pipelining)."""
         slot = k % self.depth
         if self.work[slot] is not None:
             self.work[slot].wait()      # stream-level wait for NCCL, blocking wait for gloo
             self.work[slot] = None
+            if host_sync and self.send[slot].is_cuda:
+                torch.cuda.current_stream(self.send[slot].device).synchronize()
         return self.send[slot]
 
     def launch(self, k):
