@@ -239,6 +239,66 @@ int tpamd_sample_pose_splines_host(tpamd_engine *engine, int num_paths, int num_
                                    const double *translation_points, const double *rotation_points,
                                    const double *path_start, const double *delta, double *poses);
 
+/* ------------------------------------------------------------------------
+ * Receding-horizon planning: the window loop of PathTimingTrajectory::Plan
+ * (path_timing_trajectory.cc:628-660 around ComputeTimingProfile :307-475) for B planners with
+ * TimeableJointSplinePath paths of one shape, CHAINED ON THE DEVICE. Per iteration and planner:
+ * the window start is looked up in the planner's window history (the sample before the loop's
+ * start time, :328-339; a new path starts at 0), the path is sampled and solved from there, the
+ * start velocity of a new or modified path is projected on the start tangent (:360-393), the
+ * window replaces the tail of the history (:418-472), and the loop continues from the start of
+ * the final deceleration -- max(last_extremal_index, N/2) (:639-646), converted with the
+ * nanosecond truncation of trajectory_planning/time.h:22-29 -- until the path's end is planned
+ * (CloseToEnd, timeable_path_joint_spline.cc:142-144) or the time horizon is covered (:650-652).
+ * Only the number of planners still looping crosses PCIe per iteration; histories and results
+ * cross once per call. Host pointers; in/out arrays carry planner state between calls.
+ * ------------------------------------------------------------------------ */
+#define TPAMD_PLAN_OK 0
+#define TPAMD_PLAN_FAILED_PRECONDITION 1 /* nothing to connect to (:324) */
+#define TPAMD_PLAN_OUT_OF_RANGE 2
+#define TPAMD_PLAN_INVALID_ARGUMENT 3    /* non-positive duration (:313-317), start velocity (:387-392) */
+#define TPAMD_PLAN_INTERNAL 4            /* solver set-up / optimisation failed (:394-417) */
+#define TPAMD_PLAN_DEADLINE_EXCEEDED 5   /* planning-loop limit (:655-658) */
+#define TPAMD_PLAN_MORE 100              /* history_capacity exhausted: call again with more room */
+
+typedef struct tpamd_plan_args {
+  int32_t num_planners, num_dofs, num_samples, num_points;
+  int32_t history_capacity;        /* samples per planner the history arrays hold (their stride) */
+  int32_t max_planning_iterations; /* PathTimingTrajectoryOptions::GetMaxPlanningIterations */
+  double constraint_safety;        /* PathOptions::constraint_safety */
+  double max_initial_velocity_error;
+  const double *knots, *control_points;          /* [B][P+3], [B][P][D] */
+  const double *max_velocity, *max_acceleration; /* [B][D] */
+  const double *delta;                           /* [B] PathOptions::delta_parameter */
+  const double *initial_velocity;                /* [B][D] TimeablePath::GetInitialVelocity */
+  const int64_t *start_ns, *horizon_ns;          /* [B] Plan(start, time_horizon) */
+  /* planner state, in/out */
+  int32_t *path_state;      /* [B] 1 kNewPath, 2 kModifiedPath, 3 kPathWasSampled */
+  int32_t *planned_to_end;  /* [B] in: planned_to_end_ after UpdatePathTrackingStatus */
+  int32_t *history_count;   /* [B] size of time_at_path_samples_ */
+  double *history_time, *history_s, *history_sd, *history_sdd; /* [B][capacity] *_at_path_samples_ */
+  double *history_q, *history_qd, *history_qdd;                /* [B][capacity][D] */
+  double *path_horizon;             /* [B] path_horizon_ */
+  int64_t *final_decel_start_ns;    /* [B] final_decel_start_ as left by the loop (:645-646) */
+  /* the last window each planner solved in this call: profile_ and the path's samples (out) */
+  double *window_time, *window_s, *window_sd, *window_sdd, *window_sd2; /* [B][N] */
+  double *window_q, *window_q1, *window_q2;                             /* [B][N][D] */
+  double *window_path_start, *window_sd_start, *window_time_start;      /* [B] path_start_, path_start_velocity_, path_time_start_ */
+  int32_t *window_last_extremal_index;  /* [B] */
+  double *window_max_time_increment;    /* [B] */
+  int32_t *status;   /* [B] TPAMD_PLAN_* */
+  int32_t *windows;  /* [B] windows solved in this call (0: the outputs above are untouched) */
+  /* Continuation after TPAMD_PLAN_MORE: the loop state of every planner, written by every call;
+   * with resume != 0 it is read back in (call again with larger history arrays, same other
+   * arguments), and only planners with looping[b] != 0 go on. */
+  int32_t resume;
+  int64_t *loop_start_ns;  /* [B] loop_start_time of the next window (:659) */
+  int32_t *loop_count;     /* [B] windows counted by the loop so far (:633) */
+  int32_t *looping;        /* [B] */
+} tpamd_plan_args;
+
+int tpamd_plan_joint_windows_host(tpamd_engine *engine, const tpamd_plan_args *args);
+
 /* Batched TimeOptimalPathProfile::FindMaxSd2Simplex (time_optimal_path_timing.cc:1149-1363)
  * on num_lps independent constraint sets of C rows each ([num_lps][C] arrays);
  * outputs sd2max/sddmax/sd2zero [num_lps]. Host pointers. */

@@ -569,7 +569,9 @@ static void TestPlanAgainstOracle() {
       for (int i = 0; i < 4 + k % 3; i++) { VectorXd v(D); for (int d = 0; d < D; d++) v[d] = 5.0 * rnd() - 2.5; wps.push_back(v); }
       auto probe = std::make_shared<TimeableJointSplinePath>(JointPathOptions().set_num_dofs(D).set_num_path_samples(N));
       probe->SetWaypoints({wps.data(), wps.size()});
-      const double delta = 0.35 * probe->knots().back() / (N - 1);
+      // the last planner needs some 25 windows in one call: more than the first history the
+      // mirror sends up can take, so the engine call is resumed (TPAMD_PLAN_MORE)
+      const double delta = (k == K - 1 ? 0.05 : 0.35) * probe->knots().back() / (N - 1);
       paths[k] = std::make_shared<TimeableJointSplinePath>(
           JointPathOptions().set_num_dofs(D).set_num_path_samples(N).set_delta_parameter(delta));
       std::vector<double> vmax(D), amax(D);

@@ -488,9 +488,13 @@ int tpamd_engine_reserve(tpamd_engine *e, int B, int N, int C) {
 
 size_t tpamd_engine_workspace_bytes(const tpamd_engine *e) { return e ? e->ws_bytes : 0; }
 
-int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
-                                  const tpamd_joint_inputs *in, const tpamd_path_outputs *out,
-                                  void *hip_stream) {
+}  // extern "C"
+
+namespace {
+// The joint-space solve; `plan` (window chaining, tpamd_plan_joint_windows_host) adds two small
+// kernels: skip marks after the set-up kernel, the start-velocity projection after K1.
+int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_inputs *in,
+                const tpamd_path_outputs *out, void *hip_stream, const PlanParams *plan) {
   if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
   const int B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples, P = bt->num_points;
   if (B <= 0) return B == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
@@ -506,7 +510,7 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   // stage goes to the engine's stream, ordered only behind the sweep that last used this
   // workspace -- not behind the caller's stream (see tpamd_engine_set_pipelining). A stream that
   // is being captured into a graph cannot fork into the engine's stream: plain order then.
-  bool piped = e->pipelining != 0;
+  bool piped = e->pipelining != 0 && plan == nullptr;
   if (piped) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) piped = false;
@@ -531,6 +535,8 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
                        bt->constraint_safety, in->max_velocity, in->max_acceleration,
                        in->path_start, in->delta, in->sd_start, in->sdd_start, in->time_start,
                        ws);
+    if (plan)
+      hipLaunchKernelGGL(k_plan_mark_skipped, dim3((B + 127) / 128), dim3(128), 0, fs, *plan, ws);
   }
   {
     Timer t(e, fs, KI_SAMPLE_LP);
@@ -553,6 +559,7 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
     else if (D == 8 && !e->force_generic) TPAMD_K1(8);
     else TPAMD_K1(0);
 #undef TPAMD_K1
+    if (plan) hipLaunchKernelGGL(k_plan_project, dim3((B + 127) / 128), dim3(128), 0, fs, *plan, ws);
   }
   // Mode 2: the sweep goes to one of two engine streams as well, so that it can start while the
   // previous solve's slowest paths are still running; it is ordered behind this call's position
@@ -584,6 +591,194 @@ int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
   if (piped) HIPCHK(hipEventRecord(e->ev_sweep[slot], st));
   if (deferred) HIPCHK(hipStreamWaitEvent(caller, e->ev_sweep[1 - slot], 0));
   HIPCHK(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int tpamd_time_joint_paths_device(tpamd_engine *e, const tpamd_joint_batch *bt,
+                                  const tpamd_joint_inputs *in, const tpamd_path_outputs *out,
+                                  void *hip_stream) {
+  return solve_joint(e, bt, in, out, hip_stream, nullptr);
+}
+
+int tpamd_plan_joint_windows_host(tpamd_engine *e, const tpamd_plan_args *a) {
+  if (!e || !a) return TPAMD_E_INVALID_ARGUMENT;
+  if (a->num_planners <= 0) return a->num_planners == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = a->num_planners, D = a->num_dofs, N = a->num_samples, P = a->num_points,
+               cap = a->history_capacity;
+  if (D < 1 || D > 16 || N < 3 || N > 8192 || P < 3 || cap < N) return TPAMD_E_UNSUPPORTED;
+  if (!a->knots || !a->control_points || !a->max_velocity || !a->max_acceleration || !a->delta ||
+      !a->initial_velocity || !a->start_ns || !a->horizon_ns || !a->path_state || !a->planned_to_end ||
+      !a->history_count || !a->history_time || !a->history_s || !a->history_sd || !a->history_sdd ||
+      !a->history_q || !a->history_qd || !a->history_qdd || !a->path_horizon || !a->final_decel_start_ns ||
+      !a->window_time || !a->window_s || !a->window_sd || !a->window_sdd || !a->window_sd2 || !a->window_q ||
+      !a->window_q1 || !a->window_q2 || !a->window_path_start || !a->window_sd_start ||
+      !a->window_time_start || !a->window_last_extremal_index || !a->window_max_time_increment ||
+      !a->status || !a->windows || !a->loop_start_ns || !a->loop_count || !a->looping)
+    return TPAMD_E_INVALID_ARGUMENT;
+  for (size_t b = 0; b < B; b++)
+    if (a->history_count[b] < 0 || (size_t)a->history_count[b] > cap) return TPAMD_E_INVALID_ARGUMENT;
+  TPAMD_ON_DEVICE(e);
+  hipStream_t st = nullptr;
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    double *d_knots = s.take<double>(B * (P + 3)), *d_cp = s.take<double>(B * P * D);
+    double *d_vmax = s.take<double>(B * D), *d_amax = s.take<double>(B * D), *d_dl = s.take<double>(B);
+    double *d_iv = s.take<double>(B * D);
+    long long *d_start = s.take<long long>(B), *d_hor = s.take<long long>(B), *d_loop_start = s.take<long long>(B),
+              *d_fds = s.take<long long>(B);
+    int *d_state = s.take<int>(B), *d_count = s.take<int>(B), *d_pte = s.take<int>(B), *d_active = s.take<int>(B),
+        *d_old = s.take<int>(B), *d_off = s.take<int>(B), *d_loop = s.take<int>(B), *d_app = s.take<int>(B),
+        *d_win = s.take<int>(B), *d_status = s.take<int>(B), *d_nact = s.take<int>(1);
+    double *h_t = s.take<double>(B * cap), *h_s = s.take<double>(B * cap), *h_sd = s.take<double>(B * cap),
+           *h_sdd = s.take<double>(B * cap);
+    double *h_q = s.take<double>(B * cap * D), *h_qd = s.take<double>(B * cap * D), *h_qdd = s.take<double>(B * cap * D);
+    double *d_ph = s.take<double>(B), *d_ps = s.take<double>(B), *d_sd0 = s.take<double>(B), *d_t0 = s.take<double>(B),
+           *d_sdd0 = s.take<double>(B);
+    double *w_t = s.take<double>(B * N), *w_s = s.take<double>(B * N), *w_sd = s.take<double>(B * N),
+           *w_sdd = s.take<double>(B * N), *w_sd2 = s.take<double>(B * N);
+    double *w_q = s.take<double>(B * N * D), *w_qd = s.take<double>(B * N * D), *w_qdd = s.take<double>(B * N * D);
+    double *w_q1 = s.take<double>(B * N * D), *w_q2 = s.take<double>(B * N * D), *w_dtm = s.take<double>(B);
+    int32_t *w_lei = s.take<int32_t>(B), *w_st = s.take<int32_t>(B);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+      continue;
+    }
+    HIPCHK(hipMemcpyAsync(d_knots, a->knots, B * (P + 3) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_cp, a->control_points, B * P * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_vmax, a->max_velocity, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_amax, a->max_acceleration, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_dl, a->delta, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_iv, a->initial_velocity, B * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_start, a->start_ns, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_loop_start, a->resume ? a->loop_start_ns : a->start_ns, B * 8,
+                          hipMemcpyHostToDevice, st));   // :630
+    HIPCHK(hipMemcpyAsync(d_hor, a->horizon_ns, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_state, a->path_state, B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_count, a->history_count, B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_pte, a->planned_to_end, B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_ph, a->path_horizon, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d_fds, a->final_decel_start_ns, B * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h_t, a->history_time, B * cap * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h_s, a->history_s, B * cap * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h_sd, a->history_sd, B * cap * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h_sdd, a->history_sdd, B * cap * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h_q, a->history_q, B * cap * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h_qd, a->history_qd, B * cap * D * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(h_qdd, a->history_qdd, B * cap * D * 8, hipMemcpyHostToDevice, st));
+    // loop state: a planner loops while it has not planned to the end (:632); nothing solved yet
+    std::vector<int> act(B), zero(B, 0);
+    int n_active = 0;
+    for (size_t b = 0; b < B; b++) {
+      act[b] = a->resume ? (a->looping[b] != 0) : (a->planned_to_end[b] ? 0 : 1);
+      n_active += act[b];
+    }
+    HIPCHK(hipMemcpyAsync(d_active, act.data(), B * 4, hipMemcpyHostToDevice, st));
+    for (int *z : {d_old, d_off, d_loop, d_app, d_win, d_status})
+      HIPCHK(hipMemcpyAsync(z, zero.data(), B * 4, hipMemcpyHostToDevice, st));
+    if (a->resume) HIPCHK(hipMemcpyAsync(d_loop, a->loop_count, B * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
+    HIPCHK(hipMemsetAsync(w_t, 0, B * N * 8, st));
+    HIPCHK(hipMemsetAsync(d_ps, 0, B * 8, st));
+    HIPCHK(hipMemsetAsync(d_sd0, 0, B * 8, st));
+    HIPCHK(hipMemsetAsync(d_t0, 0, B * 8, st));
+    HIPCHK(hipMemsetAsync(w_lei, 0, B * 4, st));
+    HIPCHK(hipMemsetAsync(w_dtm, 0, B * 8, st));
+    PlanParams p{};
+    p.B = (int)B; p.N = (int)N; p.D = (int)D; p.K = (int)P + 3; p.cap = (int)cap;
+    p.max_iterations = a->max_planning_iterations;
+    p.max_initial_velocity_error = a->max_initial_velocity_error;
+    p.knots = d_knots; p.delta = d_dl; p.initial_velocity = d_iv; p.start_ns = d_start; p.horizon_ns = d_hor;
+    p.path_state = d_state; p.count = d_count; p.h_time = h_t; p.h_s = h_s; p.h_sd = h_sd; p.h_sdd = h_sdd;
+    p.h_q = h_q; p.h_qd = h_qd; p.h_qdd = h_qdd; p.planned_to_end = d_pte; p.path_horizon = d_ph;
+    p.final_decel_start_ns = d_fds; p.active = d_active; p.old_state = d_old; p.offset = d_off; p.loop = d_loop;
+    p.append = d_app; p.windows = d_win; p.status = d_status; p.loop_start_ns = d_loop_start; p.num_active = d_nact;
+    p.path_start = d_ps; p.sd_start = d_sd0; p.time_start = d_t0;
+    p.w_time = w_t; p.w_s = w_s; p.w_sd = w_sd; p.w_sdd = w_sdd; p.w_q = w_q; p.w_qd = w_qd; p.w_qdd = w_qdd;
+    p.w_status = w_st; p.w_lei = w_lei;
+    tpamd_joint_batch bt{(int)B, (int)D, (int)N, (int)P, 0, 0, a->constraint_safety};
+    tpamd_joint_inputs din{d_knots, d_cp, d_vmax, d_amax, d_ps, d_dl, d_sd0, d_sdd0, d_t0, nullptr};
+    tpamd_path_outputs dout{w_t, w_s, w_sd, w_sdd, w_q, w_qd, w_qdd, w_lei, w_dtm, w_st, w_sd2};
+    const unsigned gb = (unsigned)((B + 127) / 128);
+    bool any_window = false;
+    {
+      bool full = false;
+      for (size_t b = 0; b < B; b++)
+        if (act[b] && (size_t)a->history_count[b] + N > cap) full = true;
+      if (full) n_active = 0;           // reported as TPAMD_PLAN_MORE below (d_active is untouched)
+    }
+    while (n_active > 0) {
+      // every planner's history must be able to take one more window wherever it connects
+      hipLaunchKernelGGL(k_plan_begin, dim3(gb), dim3(128), 0, st, p, e->ws);
+      int rc = solve_joint(e, &bt, &din, &dout, st, &p);
+      if (rc) return rc;
+      any_window = true;
+      HIPCHK(hipMemsetAsync(d_nact, 0, 4, st));
+      hipLaunchKernelGGL(k_plan_end, dim3(gb), dim3(128), 0, st, p);
+      hipLaunchKernelGGL(k_plan_append, dim3((unsigned)((N + 127) / 128), (unsigned)B), dim3(128), 0, st, p);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipMemcpyAsync(&n_active, d_nact, 4, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      if (n_active > 0) {
+        // capacity for the next round: count + N must fit for every looping planner
+        std::vector<int> cnt(B), actv(B);
+        HIPCHK(hipMemcpy(cnt.data(), d_count, B * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(actv.data(), d_active, B * 4, hipMemcpyDeviceToHost));
+        bool full = false;
+        for (size_t b = 0; b < B; b++)
+          if (actv[b] && (size_t)cnt[b] + N > cap) full = true;
+        if (full) break;      // the caller continues with a larger history (status stays 0, planners stay looping)
+      }
+    }
+    if (any_window) {
+      const size_t total = B * N * D;
+      hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (int)B, (int)N,
+                         (int)D, e->ws.q12, w_q1, w_q2);
+      HIPCHK(hipGetLastError());
+    } else {
+      HIPCHK(hipMemsetAsync(w_q1, 0, B * N * D * 8, st));
+      HIPCHK(hipMemsetAsync(w_q2, 0, B * N * D * 8, st));
+    }
+    HIPCHK(hipMemcpyAsync(a->path_state, d_state, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->planned_to_end, d_pte, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_count, d_count, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_time, h_t, B * cap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_s, h_s, B * cap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_sd, h_sd, B * cap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_sdd, h_sdd, B * cap * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_q, h_q, B * cap * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_qd, h_qd, B * cap * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->history_qdd, h_qdd, B * cap * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->path_horizon, d_ph, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->final_decel_start_ns, d_fds, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_time, w_t, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_s, w_s, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_sd, w_sd, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_sdd, w_sdd, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_sd2, w_sd2, B * N * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_q, w_q, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_q1, w_q1, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_q2, w_q2, B * N * D * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_path_start, d_ps, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_sd_start, d_sd0, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_time_start, d_t0, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_last_extremal_index, w_lei, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->window_max_time_increment, w_dtm, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->status, d_status, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->windows, d_win, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(act.data(), d_active, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->loop_start_ns, d_loop_start, B * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(a->loop_count, d_loop, B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    // planners that are still looping stopped because a history is full
+    for (size_t b = 0; b < B; b++) {
+      a->looping[b] = act[b];
+      if (a->status[b] == 0 && act[b]) a->status[b] = TPAMD_PLAN_MORE;
+    }
+  }
   return 0;
 }
 

@@ -28,7 +28,8 @@ enum : uint32_t {
   kErrSRange = 2u,        // .cc:185
   kErrSdStartNeg = 4u,    // .cc:190
   kErrLowerGeUpper = 8u,  // .cc:557
-  kErrTooFew = 16u        // .cc:568
+  kErrTooFew = 16u,       // .cc:568
+  kErrSkip = 32u          // engine-internal: the path takes no part in this solve (window chaining)
 };
 
 __device__ __forceinline__ bool is_tiny(double v) { return fabs(v) < kTiny; }

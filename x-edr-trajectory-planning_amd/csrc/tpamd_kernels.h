@@ -1367,6 +1367,7 @@ k_sweep(int stride, int max_loops, Source src, Workspace ws, double *t_out, doub
   const int N = path_samples(ws, b, stride);
   const size_t pb = (size_t)b * stride;
   const uint32_t bits = ws.err_bits[b];
+  if (bits & kErrSkip) return;          // not part of this solve: outputs stay as they are
   if (bits) {
     if (lane == 0) {
       status_out[b] = status_from_bits(bits);
@@ -1449,6 +1450,177 @@ __global__ void k_epilogue(int B, int N, int D, const double *rec, const double 
     if (acc > am) acc = am;
     qdd[e] = acc;
   }
+}
+
+
+// -------------------------------------------------------- receding-horizon window chaining
+// PathTimingTrajectory::Plan's window loop (path_timing_trajectory.cc:628-660 around
+// ComputeTimingProfile :307-475) for B planners with joint-space spline paths, chained on the
+// device: every iteration is k_plan_begin -> set-up -> K1 -> k_plan_project -> sweep ->
+// k_plan_end -> k_plan_append, and only the number of planners still looping travels to the host.
+// Planner state lives in the PlanParams arrays (a window history of `cap` samples per planner:
+// the reference's *_at_path_samples_ vectors). Times are int64 nanoseconds; TimeFromSec truncates
+// seconds * 1e9, TimeToSec divides by 1e9 (trajectory_planning/time.h:22-29).
+struct PlanParams {
+  int B, N, D, K, cap, max_iterations;
+  double max_initial_velocity_error;
+  const double *knots;             // [B][K]
+  const double *delta;             // [B]
+  const double *initial_velocity;  // [B][D]
+  const long long *start_ns, *horizon_ns;   // [B] arguments of Plan
+  // planner state (in/out)
+  int *path_state;                 // [B] 1 new, 2 modified, 3 sampled (timeable_path.h:94-103)
+  int *count;                      // [B] samples in the window history
+  double *h_time, *h_s, *h_sd, *h_sdd;      // [B][cap]
+  double *h_q, *h_qd, *h_qdd;               // [B][cap][D]
+  int *planned_to_end;             // [B]
+  double *path_horizon;            // [B]
+  long long *final_decel_start_ns; // [B]
+  // loop state
+  int *active, *old_state, *offset, *loop, *append, *windows, *status;
+  long long *loop_start_ns;
+  int *num_active;                 // [1]
+  // scalars of the window being solved (inputs of set-up / K1 / sweep)
+  double *path_start, *sd_start, *time_start;   // [B]
+  // outputs of the window just solved
+  const double *w_time, *w_s, *w_sd, *w_sdd, *w_q, *w_qd, *w_qdd;   // [B][N](x D)
+  const int *w_status, *w_lei;
+};
+enum { kPlanOk = 0, kPlanFailedPrecondition = 1, kPlanOutOfRange = 2, kPlanInvalidArgument = 3,
+       kPlanInternal = 4, kPlanDeadlineExceeded = 5 };
+
+// where the next window starts (path_timing_trajectory.cc:318-341)
+__global__ void k_plan_begin(PlanParams p, Workspace ws) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  if (!p.active[b]) return;
+  const long long duration = p.start_ns[b] + p.horizon_ns[b] - p.loop_start_ns[b];
+  if (duration <= 0) { p.status[b] = kPlanInvalidArgument; p.active[b] = 0; return; }   // :313-317
+  const double start_sec = (double)p.loop_start_ns[b] / 1e9;
+  const int old_state = p.path_state[b];
+  p.old_state[b] = old_state;
+  int offset = 0;
+  if (old_state == 1) {
+    p.path_start[b] = 0.0;
+    p.sd_start[b] = 0.0;
+    p.time_start[b] = start_sec;
+  } else {
+    const int num = p.count[b];
+    if (num == 0) { p.status[b] = kPlanFailedPrecondition; p.active[b] = 0; return; }
+    const double *ht = p.h_time + (size_t)b * p.cap;
+    int lo = 0, hi = num;                       // lower_bound(time_at_path_samples_, start_sec)
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (ht[mid] < start_sec) lo = mid + 1; else hi = mid;
+    }
+    offset = min(max(lo - 1, 0), num - 1);
+    p.path_start[b] = p.h_s[(size_t)b * p.cap + offset];
+    p.sd_start[b] = p.h_sd[(size_t)b * p.cap + offset];
+    p.time_start[b] = ht[offset];
+  }
+  p.offset[b] = offset;
+  p.path_horizon[b] = p.path_start[b] + p.delta[b] * (p.N - 1);
+  p.path_state[b] = 3;                          // SamplePath: kPathWasSampled
+}
+
+// skip marks for the planners that are not looping (after set-up wrote the error bits)
+__global__ void k_plan_mark_skipped(PlanParams p, Workspace ws) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  if (!p.active[b]) ws.err_bits[b] |= kErrSkip;
+}
+
+// least-squares start velocity along the start tangent (path_timing_trajectory.cc:360-393),
+// after K1 has sampled the window: q'(0) is the first record's first components
+__global__ void k_plan_project(PlanParams p, Workspace ws) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  if (!p.active[b]) return;
+  const int old_state = p.old_state[b];
+  if (old_state != 1 && old_state != 2) return;
+  const int D = p.D;
+  const double *rec0 = ws.q12 + (size_t)b * p.N * (2 * D + 2);
+  const double *iv = p.initial_velocity + (size_t)b * D;
+  double nrm2 = 0.0;
+  for (int d = 0; d < D; d++) nrm2 += rec0[2 * d] * rec0[2 * d];
+  double v = p.sd_start[b];
+  if (nrm2 > 100 * DBL_EPSILON) {
+    double dot = 0.0;
+    for (int d = 0; d < D; d++) dot += iv[d] * rec0[2 * d];
+    const double q = dot / nrm2;
+    v = (q > 0.0) ? q : 0.0;
+  }
+  double max_err = 0.0;
+  for (int d = 0; d < D; d++) {
+    const double e = fabs(rec0[2 * d] * v - iv[d]);
+    if (e > max_err) max_err = e;
+  }
+  if (max_err > p.max_initial_velocity_error) {
+    p.status[b] = kPlanInvalidArgument;
+    p.active[b] = 0;
+    ws.err_bits[b] |= kErrSkip;
+    return;
+  }
+  p.sd_start[b] = v;
+  ws.sd_start[b] = v;
+}
+
+// loop bookkeeping after a window (path_timing_trajectory.cc:639-660)
+__global__ void k_plan_end(PlanParams p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  p.append[b] = 0;
+  if (!p.active[b]) return;
+  const int st = p.w_status[b];
+  if (st != 0) { p.status[b] = kPlanInternal; p.active[b] = 0; return; }   // :394-417
+  p.append[b] = 1;
+  p.windows[b] += 1;
+  const int N = p.N;
+  const double *t = p.w_time + (size_t)b * N;
+  const int lei = p.w_lei[b];
+  const int decel_start = max(lei, N / 2);
+  p.final_decel_start_ns[b] = (long long)(t[decel_start] * 1e9);
+  const double kend = p.knots[(size_t)b * p.K + p.K - 1];
+  const int planned_to_end = p.path_horizon[b] >= kend - 1e-4;     // CloseToEnd, kSmall
+  p.planned_to_end[b] = planned_to_end;
+  const bool reached = (t[N - 1] - (double)p.start_ns[b] / 1e9) > (double)p.horizon_ns[b] / 1e9;
+  if (p.loop[b] >= p.max_iterations) { p.status[b] = kPlanDeadlineExceeded; p.active[b] = 0; return; }
+  p.loop_start_ns[b] = p.final_decel_start_ns[b];
+  p.loop[b] += 1;
+  if (planned_to_end || reached) p.active[b] = 0;
+  else atomicAdd(p.num_active, 1);
+}
+
+// drop what the window replaces and append it (path_timing_trajectory.cc:418-472)
+__global__ void k_plan_append(PlanParams p) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.N || !p.append[b]) return;
+  const int N = p.N, D = p.D;
+  const size_t src = (size_t)b * N + i;
+  const size_t dst = (size_t)b * p.cap + p.offset[b] + i;
+  if (p.offset[b] + N > p.cap) return;          // the host checks the capacity beforehand
+  p.h_time[dst] = p.w_time[src];
+  p.h_s[dst] = p.w_s[src];
+  p.h_sd[dst] = p.w_sd[src];
+  p.h_sdd[dst] = p.w_sdd[src];
+  for (int d = 0; d < D; d++) {
+    p.h_q[dst * D + d] = p.w_q[src * D + d];
+    p.h_qd[dst * D + d] = p.w_qd[src * D + d];
+    p.h_qdd[dst * D + d] = p.w_qdd[src * D + d];
+  }
+  if (i == 0) p.count[b] = p.offset[b] + N;
+}
+
+// (q', q'') pairs of the records -> separate [B][N][D] arrays (GetFirst/SecondPathDerivativeAt)
+__global__ void k_unpack_records(int B, int N, int D, const double *rec, double *q1, double *q2) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (size_t)B * N * D) return;
+  const size_t o = e / D;
+  const int d = (int)(e - o * D);
+  const double *r = rec + o * (2 * D + 2) + 2 * d;
+  q1[e] = r[0];
+  q2[e] = r[1];
 }
 
 // ------------------------------------------------------------------ s(t) query

@@ -1239,6 +1239,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   const int N = path_samples(ws, b, stride);   // samples of this path; arrays use `stride`
   const size_t pb = (size_t)b * stride;
   const uint32_t bits = ws.err_bits[b];
+  if (bits & kErrSkip) return;          // not part of this solve: outputs stay as they are
   if (bits) {
     if (tid == 0) {
       status_out[b] = status_from_bits(bits);

@@ -127,6 +127,7 @@ ABI_SYMBOLS = [
     "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
     "tpamd_time_cartesian_paths_device", "tpamd_time_cartesian_paths_host",
     "tpamd_sample_pose_splines_device", "tpamd_sample_pose_splines_host",
+    "tpamd_plan_joint_windows_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
     "tpamd_resample_uniform_host", "tpamd_resample_skip_device", "tpamd_resample_skip_host",
     "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",

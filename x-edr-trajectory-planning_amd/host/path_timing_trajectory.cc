@@ -170,11 +170,13 @@ Status PathTimingTrajectory::ProjectStartVelocity(const Window &w) {
   return OkStatus();
 }
 
-// Windows of TimeableJointSplinePath planners with equal shapes: ONE sampling call and ONE
-// solve for all of them (B = ids.size()).
-void PathTimingTrajectory::SolveJointWindows(const std::vector<PathTimingTrajectory *> &planners,
-                                             std::vector<Window> *windows, const std::vector<size_t> &ids,
-                                             std::vector<Status> *status) {
+// All windows a Plan() call needs, for the TimeableJointSplinePath planners of one shape, chained
+// on the device (tpamd_plan_joint_windows_host: path_timing_trajectory.cc:628-660 around
+// ComputeTimingProfile :307-475). The planners' window histories go up once, the extended
+// histories and each planner's last window come back once.
+void PathTimingTrajectory::PlanJointWindowsOnDevice(const std::vector<PathTimingTrajectory *> &planners,
+                                                    const std::vector<size_t> &ids, Time start,
+                                                    Duration time_horizon, std::vector<Status> *status) {
   tpamd_engine *engine = ::tpamd::shared_engine();
   if (!engine) {
     for (size_t id : ids) (*status)[id] = InternalError("no GPU engine");
@@ -183,8 +185,12 @@ void PathTimingTrajectory::SolveJointWindows(const std::vector<PathTimingTraject
   const size_t B = ids.size();
   auto *first = dynamic_cast<TimeableJointSplinePath *>(planners[ids[0]]->path_.get());
   const size_t D = first->NumDofs(), N = first->NumPathSamples(), P = first->num_control_points();
-  std::vector<double> knots(B * (P + 3)), cps(B * P * D), vmax(B * D), amax(B * D), ps(B), dl(B), sd0(B),
-      sdd0(B), t0(B);
+  std::vector<double> knots(B * (P + 3)), cps(B * P * D), vmax(B * D), amax(B * D), dl(B), iv(B * D);
+  std::vector<int64_t> start_ns(B, ::tpamd::compat::ToUnixNanos(start)), horizon_ns(B, time_horizon.nanos());
+  std::vector<int32_t> path_state(B), pte(B), count(B);
+  size_t max_count = 0;
+  int max_iterations = 0;
+  double max_velocity_error = 0.0;
   for (size_t g = 0; g < B; g++) {
     PathTimingTrajectory *pl = planners[ids[g]];
     auto *joint = dynamic_cast<TimeableJointSplinePath *>(pl->path_.get());
@@ -194,62 +200,153 @@ void PathTimingTrajectory::SolveJointWindows(const std::vector<PathTimingTraject
     for (size_t d = 0; d < D; d++) {
       vmax[g * D + d] = joint->GetMaxJointVelocity()[d];
       amax[g * D + d] = joint->GetMaxJointAcceleration()[d];
+      iv[g * D + d] = joint->GetInitialVelocity()[d];
     }
-    ps[g] = pl->path_start_; dl[g] = (*windows)[ids[g]].delta;
+    dl[g] = joint->GetPathSamplingDistance();
+    switch (joint->GetState()) {
+      case TimeablePath::State::kNewPath: path_state[g] = 1; break;
+      case TimeablePath::State::kModifiedPath: path_state[g] = 2; break;
+      case TimeablePath::State::kPathWasSampled: path_state[g] = 3; break;
+      default: path_state[g] = 0; break;
+    }
+    pte[g] = pl->planned_to_end_ ? 1 : 0;
+    count[g] = (int32_t)pl->time_at_path_samples_.size();
+    max_count = std::max(max_count, pl->time_at_path_samples_.size());
+    // the engine call takes one limit for the group; planners of one shape share their options in
+    // every use we know of, the strictest one is applied otherwise
+    max_iterations = g == 0 ? pl->options_.GetMaxPlanningIterations()
+                            : std::min(max_iterations, pl->options_.GetMaxPlanningIterations());
+    max_velocity_error = g == 0 ? pl->options_.GetMaxInitialVelocityError()
+                                : std::min(max_velocity_error, pl->options_.GetMaxInitialVelocityError());
   }
-  // sampling first: the start velocity is projected on q'(0) before the solve
-  std::vector<double> q(B * N * D), q1(B * N * D), q2(B * N * D);
-  {
-    ::tpamd::EngineGuard guard;
-    const int rc = tpamd_sample_joint_paths_host(engine, (int)B, (int)D, (int)N, (int)P, knots.data(), cps.data(),
-                                                 ps.data(), dl.data(), q.data(), q1.data(), q2.data());
+  std::vector<double> ph(B), wps(B), wsd0(B), wt0(B), wdtm(B);
+  std::vector<int64_t> fds(B), loop_start(B);
+  std::vector<int32_t> wlei(B), st(B), windows(B), loop_count(B), looping(B);
+  std::vector<double> wt(B * N), ws(B * N), wsd(B * N), wsdd(B * N), wsd2(B * N), wq(B * N * D), wq1(B * N * D),
+      wq2(B * N * D);
+  for (size_t g = 0; g < B; g++) {
+    ph[g] = planners[ids[g]]->path_horizon_;
+    fds[g] = ::tpamd::compat::ToUnixNanos(planners[ids[g]]->final_decel_start_);
+  }
+  size_t cap = max_count + 8 * N;
+  std::vector<double> ht, hs, hsd, hsdd, hq, hqd, hqdd;
+  auto pack_history = [&](size_t new_cap, bool from_planners) {
+    std::vector<double> nt(B * new_cap), ns(B * new_cap), nsd(B * new_cap), nsdd(B * new_cap),
+        nq(B * new_cap * D), nqd(B * new_cap * D), nqdd(B * new_cap * D);
+    for (size_t g = 0; g < B; g++) {
+      const size_t c = (size_t)count[g];
+      if (from_planners) {
+        PathTimingTrajectory *pl = planners[ids[g]];
+        std::copy_n(pl->time_at_path_samples_.begin(), c, nt.begin() + g * new_cap);
+        std::copy_n(pl->path_parameter_at_path_samples_.begin(), c, ns.begin() + g * new_cap);
+        std::copy_n(pl->path_velocity_at_path_samples_.begin(), c, nsd.begin() + g * new_cap);
+        std::copy_n(pl->path_acceleration_at_path_samples_.begin(), c, nsdd.begin() + g * new_cap);
+        std::copy_n(pl->position_at_path_samples_.begin(), c * D, nq.begin() + g * new_cap * D);
+        std::copy_n(pl->velocity_at_path_samples_.begin(), c * D, nqd.begin() + g * new_cap * D);
+        std::copy_n(pl->acceleration_at_path_samples_.begin(), c * D, nqdd.begin() + g * new_cap * D);
+      } else {
+        std::copy_n(ht.begin() + g * cap, c, nt.begin() + g * new_cap);
+        std::copy_n(hs.begin() + g * cap, c, ns.begin() + g * new_cap);
+        std::copy_n(hsd.begin() + g * cap, c, nsd.begin() + g * new_cap);
+        std::copy_n(hsdd.begin() + g * cap, c, nsdd.begin() + g * new_cap);
+        std::copy_n(hq.begin() + g * cap * D, c * D, nq.begin() + g * new_cap * D);
+        std::copy_n(hqd.begin() + g * cap * D, c * D, nqd.begin() + g * new_cap * D);
+        std::copy_n(hqdd.begin() + g * cap * D, c * D, nqdd.begin() + g * new_cap * D);
+      }
+    }
+    ht.swap(nt); hs.swap(ns); hsd.swap(nsd); hsdd.swap(nsdd); hq.swap(nq); hqd.swap(nqd); hqdd.swap(nqdd);
+    cap = new_cap;
+  };
+  pack_history(cap, true);
+  std::vector<int32_t> total_windows(B, 0);
+  std::vector<char> have_window(B, 0);
+  std::vector<double> kt(B * N), ks(B * N), ksd(B * N), ksdd(B * N), ksd2(B * N), kq(B * N * D), kq1(B * N * D),
+      kq2(B * N * D), kps(B), ksd0(B), kt0(B), kdtm(B);
+  std::vector<int32_t> klei(B);
+  for (int round = 0, resume = 0;; round++) {
+    tpamd_plan_args a{};
+    a.num_planners = (int32_t)B; a.num_dofs = (int32_t)D; a.num_samples = (int32_t)N; a.num_points = (int32_t)P;
+    a.history_capacity = (int32_t)cap;
+    a.max_planning_iterations = max_iterations;
+    a.constraint_safety = first->options().constraint_safety();
+    a.max_initial_velocity_error = max_velocity_error;
+    a.knots = knots.data(); a.control_points = cps.data(); a.max_velocity = vmax.data();
+    a.max_acceleration = amax.data(); a.delta = dl.data(); a.initial_velocity = iv.data();
+    a.start_ns = start_ns.data(); a.horizon_ns = horizon_ns.data();
+    a.path_state = path_state.data(); a.planned_to_end = pte.data(); a.history_count = count.data();
+    a.history_time = ht.data(); a.history_s = hs.data(); a.history_sd = hsd.data(); a.history_sdd = hsdd.data();
+    a.history_q = hq.data(); a.history_qd = hqd.data(); a.history_qdd = hqdd.data();
+    a.path_horizon = ph.data(); a.final_decel_start_ns = fds.data();
+    a.window_time = wt.data(); a.window_s = ws.data(); a.window_sd = wsd.data(); a.window_sdd = wsdd.data();
+    a.window_sd2 = wsd2.data(); a.window_q = wq.data(); a.window_q1 = wq1.data(); a.window_q2 = wq2.data();
+    a.window_path_start = wps.data(); a.window_sd_start = wsd0.data(); a.window_time_start = wt0.data();
+    a.window_last_extremal_index = wlei.data(); a.window_max_time_increment = wdtm.data();
+    a.status = st.data(); a.windows = windows.data();
+    a.resume = resume; a.loop_start_ns = loop_start.data(); a.loop_count = loop_count.data();
+    a.looping = looping.data();
+    int rc;
+    {
+      ::tpamd::EngineGuard guard;
+      rc = tpamd_plan_joint_windows_host(engine, &a);
+    }
     if (rc != 0) {
       for (size_t id : ids) (*status)[id] = InternalError(tpamd_error_string(rc));
       return;
     }
+    bool more = false;
+    for (size_t g = 0; g < B; g++) {
+      if (windows[g] > 0) {       // keep the planner's most recent window
+        have_window[g] = 1;
+        total_windows[g] += windows[g];
+        std::copy_n(wt.begin() + g * N, N, kt.begin() + g * N); std::copy_n(ws.begin() + g * N, N, ks.begin() + g * N);
+        std::copy_n(wsd.begin() + g * N, N, ksd.begin() + g * N); std::copy_n(wsdd.begin() + g * N, N, ksdd.begin() + g * N);
+        std::copy_n(wsd2.begin() + g * N, N, ksd2.begin() + g * N);
+        std::copy_n(wq.begin() + g * N * D, N * D, kq.begin() + g * N * D);
+        std::copy_n(wq1.begin() + g * N * D, N * D, kq1.begin() + g * N * D);
+        std::copy_n(wq2.begin() + g * N * D, N * D, kq2.begin() + g * N * D);
+        kps[g] = wps[g]; ksd0[g] = wsd0[g]; kt0[g] = wt0[g]; kdtm[g] = wdtm[g]; klei[g] = wlei[g];
+      }
+      if (st[g] == TPAMD_PLAN_MORE) more = true;
+    }
+    if (!more || round > 64) break;
+    pack_history(2 * cap, false);   // room for more windows, then continue where the loop stopped
+    resume = 1;
   }
-  std::vector<char> live(B, 1);
   for (size_t g = 0; g < B; g++) {
     PathTimingTrajectory *pl = planners[ids[g]];
     auto *joint = dynamic_cast<TimeableJointSplinePath *>(pl->path_.get());
-    joint->AdoptSamples(pl->path_start_, &q[g * N * D], &q1[g * N * D], &q2[g * N * D]);
-    const Status st = pl->ProjectStartVelocity((*windows)[ids[g]]);
-    if (!st.ok()) { (*status)[ids[g]] = st; live[g] = 0; }
-    sd0[g] = pl->path_start_velocity_; sdd0[g] = pl->path_start_acceleration_; t0[g] = pl->path_time_start_;
-  }
-  std::vector<double> t(B * N), s(B * N), sd(B * N), sdd(B * N), sd2(B * N), qd(B * N * D), qdd(B * N * D),
-      dtmax(B);
-  std::vector<int32_t> lei(B, 0), st(B, -1);
-  const int max_solver_loops = (int)std::max<size_t>(100, 10 * N);
-  tpamd_joint_batch batch{(int)B, (int)D, (int)N, (int)P, max_solver_loops, 0, first->options().constraint_safety()};
-  tpamd_joint_inputs in{knots.data(), cps.data(), vmax.data(), amax.data(), ps.data(), dl.data(),
-                        sd0.data(), sdd0.data(), t0.data(), nullptr};
-  tpamd_path_outputs out{t.data(), s.data(), sd.data(), sdd.data(), q.data(), qd.data(), qdd.data(),
-                         lei.data(), dtmax.data(), st.data(), sd2.data()};
-  {
-    ::tpamd::EngineGuard guard;
-    const int rc = tpamd_time_joint_paths_host(engine, &batch, &in, &out);
-    if (rc != 0) {
-      for (size_t id : ids) (*status)[id] = InternalError(tpamd_error_string(rc));
-      return;
+    if (have_window[g]) {
+      const size_t c = (size_t)count[g];
+      pl->time_at_path_samples_.assign(ht.begin() + g * cap, ht.begin() + g * cap + c);
+      pl->path_parameter_at_path_samples_.assign(hs.begin() + g * cap, hs.begin() + g * cap + c);
+      pl->path_velocity_at_path_samples_.assign(hsd.begin() + g * cap, hsd.begin() + g * cap + c);
+      pl->path_acceleration_at_path_samples_.assign(hsdd.begin() + g * cap, hsdd.begin() + g * cap + c);
+      pl->position_at_path_samples_.assign(hq.begin() + g * cap * D, hq.begin() + (g * cap + c) * D);
+      pl->velocity_at_path_samples_.assign(hqd.begin() + g * cap * D, hqd.begin() + (g * cap + c) * D);
+      pl->acceleration_at_path_samples_.assign(hqdd.begin() + g * cap * D, hqdd.begin() + (g * cap + c) * D);
+      pl->path_start_ = kps[g];
+      pl->path_start_velocity_ = ksd0[g];
+      pl->path_time_start_ = kt0[g];
+      pl->path_horizon_ = ph[g];
+      pl->planned_to_end_ = pte[g] != 0;
+      pl->final_decel_start_ = ::tpamd::compat::FromUnixNanos(fds[g]);
+      joint->AdoptSamples(kps[g], &kq[g * N * D], &kq1[g * N * D], &kq2[g * N * D]);
+      pl->profile_.AdoptSolution((int)N, (int)(2 * D), kps[g], ph[g], &kt[g * N], &ks[g * N], &ksd[g * N],
+                                 &ksdd[g * N], &ksd2[g * N], klei[g], kdtm[g]);
     }
-  }
-  for (size_t g = 0; g < B; g++) {
-    if (!live[g]) continue;
-    Window &w = (*windows)[ids[g]];
-    w.status = st[g];
-    if (st[g] >= 2 && st[g] <= 6) { (*status)[ids[g]] = InternalError("Error setting up optimization problem"); continue; }
-    if (st[g] != 0) { (*status)[ids[g]] = InternalError("Error optimizing path parameter"); continue; }
-    auto cp = [&](std::vector<double> &dst, const std::vector<double> &src, size_t n) {
-      std::copy_n(src.begin() + g * n, n, dst.begin());
-    };
-    cp(w.t, t, N); cp(w.s, s, N); cp(w.sd, sd, N); cp(w.sdd, sdd, N); cp(w.sd2, sd2, N);
-    cp(w.q, q, N * D); cp(w.qd, qd, N * D); cp(w.qdd, qdd, N * D);
-    w.last_extremal_index = lei[g]; w.max_time_increment = dtmax[g];
-    PathTimingTrajectory *pl = planners[ids[g]];
-    pl->profile_.AdoptSolution((int)N, (int)(2 * D), pl->path_start_, pl->path_horizon_, w.t.data(), w.s.data(),
-                               w.sd.data(), w.sdd.data(), w.sd2.data(), w.last_extremal_index,
-                               w.max_time_increment);
+    switch (st[g]) {
+      case TPAMD_PLAN_OK: break;
+      case TPAMD_PLAN_FAILED_PRECONDITION:
+        (*status)[ids[g]] = FailedPreconditionError("no previous window to connect to"); break;
+      case TPAMD_PLAN_INVALID_ARGUMENT:
+        (*status)[ids[g]] = InvalidArgumentError(
+            "Duration must be positive / could not satisfy initial velocity (probably not parallel to "
+            "initial tangent)");
+        break;
+      case TPAMD_PLAN_DEADLINE_EXCEEDED:
+        (*status)[ids[g]] = DeadlineExceededError("Reached maximum number of planning loops"); break;
+      default: (*status)[ids[g]] = InternalError("Error optimizing path parameter"); break;
+    }
   }
 }
 
@@ -439,9 +536,25 @@ std::vector<Status> PathTimingTrajectory::PlanBatch(const std::vector<PathTiming
     // the loop condition of path_timing_trajectory.cc:632 is tested before the first window
     if (status[i].ok() && needs) { looping[i] = !planners[i]->planned_to_end_; finish[i] = 1; }
   }
-  for (;;) {
-    // phase 1 on the host, then group the joint-spline windows by shape
+  // TimeableJointSplinePath planners: all windows of this call chained on the device, one engine
+  // call per shape group. Other TimeablePath types: the window loop on the host below.
+  {
     std::map<std::tuple<size_t, size_t, size_t, double>, std::vector<size_t>> groups;
+    for (size_t i = 0; i < P; i++) {
+      if (!finish[i]) continue;
+      if (auto *joint = dynamic_cast<TimeableJointSplinePath *>(planners[i]->path_.get())) {
+        groups[std::make_tuple(joint->NumDofs(), joint->NumPathSamples(), (size_t)joint->num_control_points(),
+                               joint->options().constraint_safety())].push_back(i);
+        looping[i] = 0;            // handled here, not by the host loop
+      }
+    }
+    for (const auto &kv : groups) {
+      PlanJointWindowsOnDevice(planners, kv.second, start, time_horizon, &status);
+      for (size_t i : kv.second)
+        if (!status[i].ok()) finish[i] = 0;
+    }
+  }
+  for (;;) {
     std::vector<size_t> foreign;
     bool any = false;
     for (size_t i = 0; i < P; i++) {
@@ -450,14 +563,9 @@ std::vector<Status> PathTimingTrajectory::PlanBatch(const std::vector<PathTiming
       PathTimingTrajectory *pl = planners[i];
       status[i] = pl->BeginWindow(loop_start[i], start + time_horizon - loop_start[i], &windows[i]);
       if (!status[i].ok()) { looping[i] = 0; finish[i] = 0; continue; }
-      if (auto *joint = dynamic_cast<TimeableJointSplinePath *>(pl->path_.get()))
-        groups[std::make_tuple(joint->NumDofs(), joint->NumPathSamples(), (size_t)joint->num_control_points(),
-                               joint->options().constraint_safety())].push_back(i);
-      else
-        foreign.push_back(i);
+      foreign.push_back(i);
     }
     if (!any) break;
-    for (const auto &kv : groups) SolveJointWindows(planners, &windows, kv.second, &status);
     for (size_t i : foreign) status[i] = planners[i]->SolveWindowOnHost(&windows[i]);
     // phase 3 and the loop bookkeeping of path_timing_trajectory.cc:640-660
     for (size_t i = 0; i < P; i++) {

@@ -77,9 +77,9 @@ class PathTimingTrajectory : public TrajectoryPlanner {
   // Plan() split around its window loop
   Status PlanPrologue(Time start, Duration time_horizon, bool *needs_windows);
   Status PlanEpilogue(Time start);
-  static void SolveJointWindows(const std::vector<PathTimingTrajectory *> &planners,
-                                std::vector<Window> *windows, const std::vector<size_t> &ids,
-                                std::vector<Status> *status);
+  static void PlanJointWindowsOnDevice(const std::vector<PathTimingTrajectory *> &planners,
+                                       const std::vector<size_t> &ids, Time start, Duration time_horizon,
+                                       std::vector<Status> *status);
   void ClampToTimeStepMultiple(Time *time);
   // path_timing_trajectory.h (reference) InterpolationResult, InterpolateAtTime :709-753
   struct InterpolationResult {
