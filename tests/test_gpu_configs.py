@@ -299,7 +299,33 @@ def test_pipelined_engine_gives_the_same_results_in_order(env):
     torch.cuda.synchronize()
     for name in keys:
         assert torch.equal(a[name], ref[name]) and torch.equal(c[name], ref1[name]), name
-    E2.set_pipelining(False)
+    # a call captured into a HIP graph cannot fork into the engine's stream: it runs unpipelined
+    E2.reserve(B, N, 2 * D)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    with torch.cuda.stream(side):
+        E2.time_joint_paths(inp, g, N, stream=side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        E2.time_joint_paths(inp1, g, N, stream=side)
+    g["time"].fill_(-1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    for name in keys:
+        assert torch.equal(g[name], ref1[name]), name
+    # mode 2: completion deferred by one call, fence() for the rest
+    E2.set_pipelining(2)
+    for it in range(6):
+        E2.time_joint_paths(inp, a, N)
+        E2.time_joint_paths(inp1, c, N)
+    E2.fence()
+    torch.cuda.synchronize()
+    for name in keys:
+        assert torch.equal(a[name], ref[name]) and torch.equal(c[name], ref1[name]), name
+    E2.set_pipelining(0)
     E2.time_joint_paths(inp, a, N)
     torch.cuda.synchronize()
     assert torch.equal(a["time"], ref["time"])
