@@ -213,9 +213,14 @@ def test_engine_leaves_the_callers_device_current(env):
     E2.close()
 
 
-@pytest.mark.parametrize("kind,D,N,B", [("joint", 7, 700, 6), ("joint", 14, 300, 3), ("joint", 3, 130, 4),
-                                        ("cartesian", 6, 500, 4)])
-def test_fused_boundary_passes_match_the_oracle_stage_by_stage(env, kind, D, N, B):
+@pytest.mark.parametrize("kind,D,N,B,vscale,ascale", [
+    ("joint", 7, 700, 6, 1.0, 1.0), ("joint", 14, 300, 3, 1.0, 1.0), ("joint", 3, 130, 4, 1.0, 1.0),
+    ("cartesian", 6, 500, 4, 1.0, 1.0),
+    # tight velocity limits: isolated velocity-limited samples (the reference's pass 2,
+    # time_optimal_path_timing.cc:1386-1395) and the deferred fixes next to them
+    ("joint", 7, 700, 8, 0.3, 1.0), ("joint", 7, 2000, 4, 0.3, 1.0), ("joint", 6, 300, 8, 0.5, 5.0),
+    ("joint", 7, 2100, 2, 0.3, 1.0), ("joint", 7, 2500, 2, 0.3, 1.0)])
+def test_fused_boundary_passes_match_the_oracle_stage_by_stage(env, kind, D, N, B, vscale, ascale):
     """The specialised sweep kernels run CalculateBoundary's passes 2-4 for their path
     (tpamd_sweep_joint.h boundary_passes_for_path). With tpamd_debug_keep_boundary the final
     curve, its sdd range and the classification are stored: bit-equal to the oracle's
@@ -226,6 +231,8 @@ def test_fused_boundary_passes_match_the_oracle_stage_by_stage(env, kind, D, N, 
     out = eng.alloc_joint_outputs(B, N, D, env["dev"])
     if kind == "joint":
         b = syn.make_joint_batch(B, D, N, first_path_index=400)
+        b["vmax"] = np.ascontiguousarray(b["vmax"] * vscale)
+        b["amax"] = np.ascontiguousarray(b["amax"] * ascale)
         E.time_joint_paths(eng.upload_joint_batch(b, env["dev"]), out, N)
     else:
         b = syn.make_cartesian_batch(B, D, N, first_path_index=400)
@@ -254,6 +261,9 @@ def test_fused_boundary_passes_match_the_oracle_stage_by_stage(env, kind, D, N, 
         np.testing.assert_array_equal(bd["sdd_max"][i], p.sdd_max_for_sd2_max)
         np.testing.assert_array_equal(bd["sdd_min"][i], p.sdd_min_for_sd2_max)
         np.testing.assert_array_equal(bd["type"][i], p.boundary_type)
+        if st == 0:
+            np.testing.assert_array_equal(out["time"][i].cpu().numpy(), p.time)
+            np.testing.assert_array_equal(out["sdd"][i].cpu().numpy(), p.sdd)
     E.close()
 
 

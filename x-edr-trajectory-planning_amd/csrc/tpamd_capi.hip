@@ -807,12 +807,18 @@ int tpamd_engine_set_pipelining(tpamd_engine *e, int on) {
       HIPCHK(hipEventCreateWithFlags(&e->ev_front[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&e->ev_sweep[k], hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&e->ev_call[k], hipEventDisableTiming));
-      HIPCHK(hipStreamCreateWithFlags(&e->sweep_stream[k], hipStreamNonBlocking));
     }
   }
+  // The sweep streams exist only once mode 2 is asked for: the runtime multiplexes streams onto a
+  // few hardware queues, and one more idle stream was measured to put the engine's stream on the
+  // caller's queue -- serialising exactly the two things mode 1 overlaps (0.66 -> 0.93 ms per step).
+  if (on == 2)
+    for (int k = 0; k < 2; k++)
+      if (!e->sweep_stream[k]) HIPCHK(hipStreamCreateWithFlags(&e->sweep_stream[k], hipStreamNonBlocking));
   if (e->pipelining && on != e->pipelining) {   // leave the old mode with nothing in flight
     HIPCHK(hipStreamSynchronize(e->aux));
-    for (int k = 0; k < 2; k++) HIPCHK(hipStreamSynchronize(e->sweep_stream[k]));
+    for (int k = 0; k < 2; k++)
+      if (e->sweep_stream[k]) HIPCHK(hipStreamSynchronize(e->sweep_stream[k]));
   }
   e->pipelining = on;
   return 0;

@@ -1049,12 +1049,236 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
 
   for (int i = tid; i < N; i += 128) at_l[i] = ws.at0[pb + i];
   __syncthreads();
+  // "isolated point" (iso_at) of every sample as a byte of its own, formed without branches: the
+  // passes below then read a handful of bytes per sample, all loads issued together, instead of
+  // walking through short-circuit conditions one LDS round trip at a time. iso_l[0] and
+  // iso_l[N-1] are 0 by definition, so reads clamped into the path need no range checks.
+  uint8_t *iso_l = ff_l + (ff_l - at_l);
+  for (int i = tid; i < N; i += 128) {
+    const int a0 = at_l[cl(i - 1)], a1 = at_l[i], a2 = at_l[cl(i + 1)];
+    iso_l[i] = (uint8_t)((i >= 1) & (i <= N - 2) & (a0 == 0) & (a1 != 0) & (a2 == 0));
+  }
+  __syncthreads();
   TPAMD_ACC(19, tp0);
+
+#ifndef TPAMD_BOUNDARY_FAST
+#define TPAMD_BOUNDARY_FAST 1
+#endif
+  // Paths of up to 2100 samples: passes 2 (second half), 3 and 4 from ONE round of loads, with no
+  // load, branch or cross-lane operation inside the per-sample arithmetic. The path is cut into
+  // chunks of 62 samples; a wave takes every other chunk and loads it with one sample of overlap
+  // on either side (lane l of chunk c holds sample 62c + l - 1, lanes 1..62 own theirs), so a
+  // neighbour's value is always the next lane's register (DPP wave shift). A sample with no
+  // isolated point and no deferred fix within reach -- about nineteen in twenty -- needs nothing
+  // but those registers in either pass. The others are listed per wave and handled one per lane
+  // from memory, with the reference's case analysis spelled out (detect_one, final_one).
+  constexpr int UF = 17;                 // chunks per wave
+  // The per-wave lists hold every sample of the wave in the worst case (they are emptied only
+  // after the register-resident part, which leaves no room for the re-fit code next to it); they
+  // follow the three byte arrays in the LDS that later holds sd2. Very short paths, where that
+  // does not fit, take the general code below.
+  const int slow_cap = ((N + 127) / 128) * 64 + 64;
+  const int flag_bytes = (int)(ff_l - at_l);
+  if (TPAMD_BOUNDARY_FAST && N <= 62 * 2 * UF && 3 * flag_bytes + 8 * slow_cap <= 8 * N) {
+    int *slow = reinterpret_cast<int *>(at_l + 3 * flag_bytes) + w * slow_cap;
+    int nslow = 0;
+    // the samples whose bit is set in `mask` (bit u: chunk 2u + w), appended to this wave's list
+    auto list_samples = [&](unsigned mask) {
+#pragma unroll
+      for (int u = 0; u < UF; u++) {
+        const bool need = (mask >> u) & 1u;
+        const unsigned long long bm = __ballot(need);
+        if (bm) {
+          if (need) slow[nslow + __popcll(bm & ((1ull << lane) - 1ull))] = 62 * (2 * u + w) + lane - 1;
+          nslow += __popcll(bm);
+        }
+      }
+    };
+    // pass 2, first half (.cc:1386-1395): FindSddMax/Min at sd2_max_for_sdd0 next to isolated
+    // points -- usually there are none, which one ballot per chunk establishes
+    {
+      unsigned zf = 0u;
+#pragma unroll
+      for (int u = 0; u < UF; u++) {
+        const int j = 62 * (2 * u + w) + lane - 1;
+        const int jb = max(j, 1);
+        zf |= (unsigned)((lane >= 1) && (lane <= 62) && (j >= 0) && (j < N) &&
+                         ((iso_l[jb - 1] | iso_l[jb + 1]) != 0)) << u;
+      }
+      list_samples(zf);
+      JointSweep<D, E>::wave_lds_sync();
+      for (int e0 = 0; e0 < nslow; e0 += 64) {
+        const bool valid = e0 + lane < nslow;
+        const int j = valid ? slow[e0 + lane] : 0;
+        // (a stray byte may have listed a sample that is not next to an isolated point: harmless,
+        // its Xz / Yz are then simply never read)
+        if (P.count + 64 > kRefitCap) P.template flush<false>(diag);
+        P.append(valid, j, valid ? z0[j] : 0.0, 0.0);
+      }
+      nslow = 0;
+      P.template flush<false>(diag);
+      __threadfence_block();
+      __syncthreads();
+      TPAMD_ACC(20, tp0);
+    }
+    // pass 2, second half for one sample, everything from memory (k_boundary_detect)
+    auto detect_one = [&](int k) {
+      uint8_t flag = 0;
+      if (k >= 1 && k <= N - 2) {
+        const bool iso_k = iso_at(at_l, N, k), iso_km1 = iso_at(at_l, N, k - 1),
+                   iso_km2 = iso_at(at_l, N, k - 2);
+        const bool l_mod = iso_k || iso_km2;
+        const double m_l = l_mod ? z0[k - 1] : m0[k - 1];
+        const double fsmax_l = l_mod ? Xz[k - 1] : X0[k - 1];
+        const double m_c = iso_km1 ? z0[k] : m0[k];
+        const double X_c = iso_km1 ? Xz[k] : X0[k];
+        const double Y_c = iso_km1 ? Xz[k] : Y0[k];
+        const double m_r = iso_k ? z0[k + 1] : m0[k + 1];
+        const double Y_r = iso_k ? Xz[k + 1] : Y0[k + 1];
+        const double fsmin_r = iso_k ? Yz[k + 1] : Y0[k + 1];
+        const double sd2p = (m_r - m_c) / ds;
+        const double sd2p_min = 2 * Y_c;
+        const double sd2p_max = 2 * X_c;
+        const bool sink_or_source = (sd2p < sd2p_min) || (sd2p > sd2p_max);
+        const bool skipped_sdd = (X_c > 0) && (Y_r < 0);
+        const bool skipped_sd2 = (m_c > m_l - kTiny) && (m_c > m_r - kTiny);
+        if ((skipped_sd2 || skipped_sdd) && sink_or_source) {
+          const double fw = m_l + 2.0 * ds * fsmax_l;
+          const double bw = m_r - 2.0 * ds * fsmin_r;
+          double mn = z0[k];
+          if (fw < mn) mn = fw;
+          if (bw < mn) mn = bw;
+          ws.fix_val[pb + k] = (0.0 < mn) ? mn : 0.0;
+          flag = 1;
+        }
+      }
+      ff_l[k] = flag;
+    };
+    auto drain_detect = [&]() {
+      JointSweep<D, E>::wave_lds_sync();
+      for (int e0 = 0; e0 < nslow; e0 += 64)
+        if (e0 + lane < nslow) detect_one(slow[e0 + lane]);
+      nslow = 0;
+      JointSweep<D, E>::wave_lds_sync();
+    };
+    double m0c[UF], X0c[UF], Y0c[UF];
+    // (indices stay affine in u wherever the chunk lies inside the path: one address register per
+    // array and immediate offsets instead of 51 clamped addresses)
+#pragma unroll
+    for (int u = 0; u < UF; u++) {
+      const int c = 2 * u + w;
+      const int k = 62 * c + lane - 1;
+      const int kc = (c >= 1 && 62 * c + 62 < N) ? k : cl(k);        // (uniform choice)
+      m0c[u] = m0[kc]; X0c[u] = X0[kc]; Y0c[u] = Y0[kc];
+    }
+    const bool owner = (lane >= 1) && (lane <= 62);
+    unsigned listed = 0u;              // bit u: this lane's sample of chunk 2u + w goes to the list
+#pragma unroll
+    for (int u = 0; u < UF; u++) {
+      const int k = 62 * (2 * u + w) + lane - 1;
+      const bool inside = owner && (k >= 1) && (k <= N - 2);
+      // unclamped byte reads: a byte from outside [0, N) can only send a sample to the list, which
+      // is always right (the reads stay inside this LDS region; lane 0 of the first chunk reads
+      // below it and owns nothing)
+      const int kb = max(k, 2);
+      const bool near_iso = (iso_l[kb] | iso_l[kb - 1] | iso_l[kb - 2]) != 0;
+      const double m_c = m0c[u], X_c = X0c[u], Y_c = Y0c[u];
+      const double m0l = dpp_f64<0x138>(m_c);                                // wave_shr:1: sample k-1
+      const double m0r = dpp_f64<0x130>(m_c), Y0r = dpp_f64<0x130>(Y_c);     // wave_shl:1: sample k+1
+      const double sd2p = (m0r - m_c) / ds;
+      const double sd2p_min = 2 * Y_c;
+      const double sd2p_max = 2 * X_c;
+      const bool sink_or_source = (sd2p < sd2p_min) || (sd2p > sd2p_max);
+      const bool skipped_sdd = (X_c > 0) && (Y0r < 0);
+      const bool skipped_sd2 = (m_c > m0l - kTiny) && (m_c > m0r - kTiny);
+      // a deferred fix needs sd2_max_for_sdd0[k] from memory: listed as well
+      const bool fix = (skipped_sd2 || skipped_sdd) && sink_or_source;
+      const bool to_list = inside && (near_iso || fix);
+      if (owner && k >= 0 && k < N && !to_list) ff_l[k] = 0;
+      listed |= (unsigned)to_list << u;
+    }
+    list_samples(listed);
+    drain_detect();
+    __threadfence_block();
+    __syncthreads();
+    TPAMD_ACC(21, tp0);
+
+    // passes 3 and 4 for one sample, everything from memory (k_boundary_final)
+    auto final_one = [&](int j, double &m, double &X, double &Y, double &m_next) -> bool {
+      bool refit = false;
+      m = 0.0; X = 0.0; Y = 0.0; m_next = 0.0;
+      const bool f_next = (j + 1 <= N - 2) && ff_l[j + 1];
+      const bool f_self = ff_l[j];
+      const bool f_prev = (j >= 1) && ff_l[j - 1];
+      const bool iso_p = iso_at(at_l, N, j - 1), iso_n = iso_at(at_l, N, j + 1);
+      if (f_next || (!f_self && f_prev)) {
+        m = z0[j];
+        if (iso_p || iso_n) { X = Xz[j]; Y = Yz[j]; }     // pass 2 was here
+        else refit = true;
+      } else if (f_self) {
+        m = fv[j];
+        refit = true;
+      } else if (iso_n) {
+        m = z0[j]; X = Xz[j]; Y = Yz[j];
+      } else if (iso_p) {
+        m = z0[j]; X = Xz[j]; Y = Xz[j];      // sic, .cc:1394-1395
+      } else {
+        m = m0[j]; X = X0[j]; Y = Y0[j];
+      }
+      const int jn = j + 1;                    // final value of element j + 1
+      if (jn <= N - 1) {
+        if (jn + 1 <= N - 2 && ff_l[jn + 1]) m_next = z0[jn];
+        else if (ff_l[jn]) m_next = fv[jn];
+        else if (ff_l[jn - 1]) m_next = z0[jn];
+        else if (iso_at(at_l, N, jn + 1) || iso_at(at_l, N, jn - 1)) m_next = z0[jn];
+        else m_next = m0[jn];
+      }
+      return refit;
+    };
+    auto drain_final = [&]() {
+      JointSweep<D, E>::wave_lds_sync();
+      for (int e0 = 0; e0 < nslow; e0 += 64) {
+        const bool valid = e0 + lane < nslow;
+        double m = 0.0, X = 0.0, Y = 0.0, m_next = 0.0;
+        bool refit = false;
+        int j = 0;
+        if (valid) {
+          j = slow[e0 + lane];
+          refit = final_one(j, m, X, Y, m_next);
+          if (!refit) P.finalize(j, m, X, Y, m_next);
+        }
+        if (P.count + 64 > kRefitCap) P.template flush<true>(diag);
+        P.append(refit, j, m, m_next);
+      }
+      nslow = 0;
+      JointSweep<D, E>::wave_lds_sync();
+    };
+    listed = 0u;
+#pragma unroll
+    for (int u = 0; u < UF; u++) {
+      const int j = 62 * (2 * u + w) + lane - 1;
+      const bool mine = owner && (j >= 0) && (j < N);
+      const int jb = max(j, 1);
+      // a deferred fix or an isolated point at j-1 .. j+2 (stray bytes only add list entries)
+      const bool busy = (ff_l[jb - 1] | ff_l[jb] | ff_l[jb + 1] | ff_l[jb + 2] |
+                         iso_l[jb - 1] | iso_l[jb] | iso_l[jb + 1] | iso_l[jb + 2]) != 0;
+      const double m0r = dpp_f64<0x130>(m0c[u]);
+      if (mine && !busy) P.finalize(j, m0c[u], X0c[u], Y0c[u], (j + 1 <= N - 1) ? m0r : 0.0);
+      listed |= (unsigned)(mine && busy) << u;
+    }
+    list_samples(listed);
+    drain_final();
+    P.template flush<true>(diag);
+    __threadfence_block();
+    __syncthreads();
+    TPAMD_ACC(22, tp0);
+    return;
+  }
 
   // pass 2, first half (.cc:1386-1395): FindSddMax/Min at sd2_max_for_sdd0 next to isolated points
   for (int base = 64 * w; base < N; base += 128) {
     const int j = base + lane;
-    const bool need = j < N && (iso_at(at_l, N, j - 1) || iso_at(at_l, N, j + 1));
+    const bool need = (j < N) & ((iso_l[cl(j - 1)] | iso_l[cl(j + 1)]) != 0);
     if (P.count + 64 > kRefitCap) P.template flush<false>(diag);
     P.append(need, j, need ? z0[j] : 0.0, 0.0);
   }
@@ -1219,11 +1443,10 @@ __host__ __device__ inline size_t sweep_joint_lds_bytes(int N) {
 // the backward wave finishes with its share (emit_range); the tail is shared by the two waves.
 // TPAMD_SWEEP_WAVES_PER_EU (build-time, A/B): ask the compiler for a register budget that lets
 // that many waves share a SIMD (3 -> 168 VGPRs).
-#ifdef TPAMD_SWEEP_WAVES_PER_EU
-#define TPAMD_SWEEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TPAMD_SWEEP_WAVES_PER_EU, TPAMD_SWEEP_WAVES_PER_EU)))
-#else
-#define TPAMD_SWEEP_OCCUPANCY
+#ifndef TPAMD_SWEEP_WAVES_PER_EU
+#define TPAMD_SWEEP_WAVES_PER_EU 2
 #endif
+#define TPAMD_SWEEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TPAMD_SWEEP_WAVES_PER_EU, TPAMD_SWEEP_WAVES_PER_EU)))
 template <int D, int E = 0>
 __global__ void __launch_bounds__(128) TPAMD_SWEEP_OCCUPANCY
 k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
@@ -1272,6 +1495,23 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   S.qdd_g = qdd_out ? qdd_out + pb * D : nullptr;
   S.end_idx = 0;
   S.tag0 = -1; S.tag1 = -1;
+  double *sd2 = S.sd2;
+  const double sd_start = ws.sd_start[b];
+#ifdef TPAMD_DIAG
+  long long(&diag)[24] = S.diag;
+  for (int k = 0; k < 24; k++) diag[k] = 0;
+#define TPAMD_DIAG_PTR S.diag
+#else
+#define TPAMD_DIAG_PTR nullptr
+#endif
+  // CalculateBoundary passes 2-4 for this path; scratch in the LDS the sweep uses afterwards
+  // (flags in the sd2 array, re-fit values in the tile rings)
+  boundary_passes_for_path<D, E>(src, ws, b, N, stride, tid, reinterpret_cast<uint8_t *>(sd2),
+                           reinterpret_cast<uint8_t *>(sd2) + LL::type_bytes(N),
+                           reinterpret_cast<char *>(ring), typel, ws.keep_boundary != 0,
+                           TPAMD_DIAG_PTR);
+  // (the boundary passes run before the per-lane constants below are loaded: they need most of
+  // the register file for themselves)
   constexpr int C = 2 * D + E;
   const double *lim_lo = src.lim + (size_t)b * 2 * C, *lim_hi = lim_lo + C;
   {
@@ -1330,21 +1570,6 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     }
   }
 
-  double *sd2 = S.sd2;
-  const double sd_start = ws.sd_start[b];
-#ifdef TPAMD_DIAG
-  long long(&diag)[24] = S.diag;
-  for (int k = 0; k < 24; k++) diag[k] = 0;
-#define TPAMD_DIAG_PTR S.diag
-#else
-#define TPAMD_DIAG_PTR nullptr
-#endif
-  // CalculateBoundary passes 2-4 for this path; scratch in the LDS the sweep uses afterwards
-  // (flags in the sd2 array, re-fit values in the tile rings)
-  boundary_passes_for_path<D, E>(src, ws, b, N, stride, tid, reinterpret_cast<uint8_t *>(sd2),
-                           reinterpret_cast<uint8_t *>(sd2) + LL::type_bytes(N),
-                           reinterpret_cast<char *>(ring), typel, ws.keep_boundary != 0,
-                           TPAMD_DIAG_PTR);
   for (int i = tid; i < N; i += 128) {
     sd2[i] = qnan();
     S.sdd_g[i] = qnan();
