@@ -423,38 +423,64 @@ struct JointSweep {
   // other candidate beats it: every candidate that compares better must be inadmissible,
   // which is checked against ONE row only, row r (the one the speculated candidate sits
   // on: anything better than it normally violates that row). A better candidate that
-  // passes row r makes the answer "unknown" (false), never wrong: the step then falls to
-  // the scalar code.
-  template <bool MAX>
-  __device__ __forceinline__ bool chain_step_exact(int j, double hi_r, f64x2 arow, double s2,
-                                                   double sddw) const {
+  // passes row r makes the answer "unknown" (true = bad), never wrong: the step then falls
+  // to the scalar code.
+  // The other candidates are only ever compared, never used: their quotient is formed with a
+  // reciprocal taken before the chain ran (rc, relative error far below 1e-6) and counts as
+  // "not better" or "violates row r" only beyond a 2e-6 margin; anything closer is "unknown".
+  // What the exact comparison would reject the screen rejects too.
+  // pvv / pown / ex: the record pairs this lane needs, loaded before the chain ran.
+  struct ChainOperands {
+    f64x2 pvv[L::VPL];
+    f64x2 pown[L::CPL];
+    double rc[L::CPL];
+    f64x2 ex;
+  };
+  __device__ __forceinline__ void load_chain_operands(int j, ChainOperands &o) const {
     const f64x2 *p = record(j);
+#pragma unroll
+    for (int i = 0; i < L::VPL; i++) o.pvv[i] = p[vv_off[i]];
+#pragma unroll
+    for (int i = 0; i < L::CPL; i++) o.pown[i] = p[v_off[i]];
+    if (E > 0) o.ex = p[D];
+#pragma unroll
+    for (int i = 0; i < L::CPL; i++) o.rc[i] = __builtin_amdgcn_rcp(o.pown[i].x);
+  }
+  template <bool MAX>
+  __device__ __forceinline__ bool chain_step_bad(const ChainOperands &o, int win_cand, double hi_r,
+                                                 f64x2 arow, double s2, double sddw) const {
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < L::VPL; i++) {       // winner against this lane's share of the rows
-      const f64x2 pr = p[vv_off[i]];
+      const f64x2 pr = o.pvv[i];
       const double v = pr.x * sddw + pr.y * s2;
       bad = bad | (v + kTiny < -va_hi[i]) | (v - kTiny > va_hi[i]);
       const double vv = (pr.x * pr.x) * s2;
       bad = bad | (vv + kTiny < 0.0) | (vv - kTiny > vv_hi[i]);
     }
     if (E > 0) {                              // extra rows (every lane: two cheap checks)
-      const f64x2 ex = p[D];
-      const double v0 = ex.x * s2, v1 = ex.y * s2;
+      const double v0 = o.ex.x * s2, v1 = o.ex.y * s2;
       bad = bad | (v0 + kTiny < -ex_hi[0]) | (v0 - kTiny > ex_hi[0]);
       bad = bad | (v1 + kTiny < -ex_hi[E - 1]) | (v1 - kTiny > ex_hi[E - 1]);
     }
+    const int p0 = lane & (L::GRP - 1);
+    const double aw = fabs(sddw);
 #pragma unroll
     for (int i = 0; i < L::CPL; i++) {       // this lane's other candidates
-      const f64x2 own = p[v_off[i]];
-      const double sddi = (v_lim[i] - own.y * s2) / own.x;
-      const bool better = MAX ? (sddi > sddw) : (sddi < sddw);
-      const double v = arow.x * sddi + arow.y * s2;
-      const bool passes = !((v + kTiny < -hi_r) | (v - kTiny > hi_r));
-      bad = bad | (better & passes & !(fabs(own.x) < kTiny));
+      const f64x2 own = o.pown[i];
+      const double lim_i = v_lim[i];
+      // no candidate here (NaN bound), a row with q' ~ 0 (the reference skips it), or the
+      // speculated candidate itself (equal, hence not better)
+      const bool skip = (lim_i != lim_i) | (fabs(own.x) < kTiny) | (p0 + L::GRP * i == win_cand);
+      const double sa = (lim_i - own.y * s2) * o.rc[i];
+      const double tol = 2e-6 * fabs(sa) + 1e-300;
+      const bool not_better = MAX ? (sa + tol < sddw - 2e-6 * aw) : (sa - tol > sddw + 2e-6 * aw);
+      const double ax = arow.x * sa;
+      const double va = ax + arow.y * s2;
+      const bool violates = fabs(va) > hi_r + 2.0 * kTiny + 2e-6 * fabs(ax) + 1e-12 * (fabs(va) + hi_r);
+      bad = bad | !(skip | not_better | violates);
     }
-    const unsigned long long bm = __ballot(bad);
-    return ((bm >> (lane & ~(L::GRP - 1))) & ((1ull << L::GRP) - 1ull)) == 0ull;
+    return bad;
   }
 
   // AreDerivativesValid (.cc:624-636): lane j < 2D checks row j. idx is always the extremal's
@@ -676,6 +702,11 @@ struct JointSweep {
     const int jn = min(max(j + dir, 0), N - 1);
     const f64x2 arow = record(j)[r];
     const double hi_r = readlane_f64(row_hi, r);
+    // everything the verification reads is requested now, so that it arrives while the chain runs
+    ChainOperands ops;
+    load_chain_operands(j, ops);
+    const f64x2 mt_j = record(j)[kMt], mt_n = record(jn)[kMt];
+    const double nxt = sd2[jn];
     // The recurrence. Its division is done with a reciprocal refined per lane beforehand
     // (the denominator-only part of the IEEE division sequence: v_rcp_f64 + two Newton
     // steps), so that one step is 7 dependent operations. Whether that quotient is the
@@ -688,36 +719,49 @@ struct JointSweep {
       e = __builtin_fma(-arow.x, y, 1.0);
       y = __builtin_fma(y, e, y);
     }
-    double cur = c.cur;
-    double my_cur = 0.0;
+    // The recurrence runs as a pipeline over the lanes instead of sixteen times the same
+    // arithmetic in every lane: in each round every step's lanes apply THEIR step (own q', q'',
+    // reciprocal: no cross-lane operand traffic) to the value in front of them, and the results
+    // move one step (four lanes) up: row_shr:4 inside a 16-lane row, row_bcast:15 into lanes 0-3
+    // of the next row. Step 0's input is the extremal's current sd2 and never changes, so after
+    // round k the input and output of step k are final and stay so; after 16 rounds every step
+    // holds the sd2 it starts from (x) and the one the chain produced for it (y).
+    static_assert(G == 4 && K == 16, "the lane pipeline below assumes four lanes per step and 16-lane DPP rows");
+    double x = c.cur, y_out = 0.0;
 #pragma unroll
     for (int s = 0; s < K; s++) {
-      const double a = readlane_f64(arow.x, G * s), b = readlane_f64(arow.y, G * s);
-      const double ys = readlane_f64(y, G * s);
-      if (k == s) my_cur = cur;
-      const double n = alim - b * cur;
-      const double q0 = n * ys;
-      const double rem = __builtin_fma(-a, q0, n);
-      const double q = __builtin_fma(rem, ys, q0);
-      cur = FWD ? cur + two_ds * q : cur - two_ds * q;
+      const double n = alim - arow.y * x;
+      const double q0 = n * y;
+      const double rem = __builtin_fma(-arow.x, q0, n);
+      const double q = __builtin_fma(rem, y, q0);
+      y_out = FWD ? x + two_ds * q : x - two_ds * q;
+      if (s + 1 < K) {
+        int lo = __double2loint(x), hi = __double2hiint(x);
+        const int ylo = __double2loint(y_out), yhi = __double2hiint(y_out);
+        lo = __builtin_amdgcn_update_dpp(lo, ylo, 0x114, 0xf, 0xf, false);    // row_shr:4
+        hi = __builtin_amdgcn_update_dpp(hi, yhi, 0x114, 0xf, 0xf, false);
+        lo = __builtin_amdgcn_update_dpp(lo, ylo, 0x142, 0xe, 0x1, false);    // row_bcast:15 -> lanes 0-3 of rows 1-3
+        hi = __builtin_amdgcn_update_dpp(hi, yhi, 0x142, 0xe, 0x1, false);
+        x = __hiloint2double(hi, lo);
+      }
     }
-    // every quad redoes its own step from the captured sd2_k with the reference's operations
+    const double my_cur = x;
+    // every quad redoes its own step from its sd2 with the reference's operations
     const double my_sdd = (alim - arow.y * my_cur) / arow.x;
     const double my_new = FWD ? my_cur + two_ds * my_sdd : my_cur - two_ds * my_sdd;
-    double chain_next = __shfl_down(my_cur, G, 64);      // what the recurrence fed to step k+1
-    if (k == K - 1) chain_next = cur;
-    const bool exact = (__double_as_longlong(chain_next) == __double_as_longlong(my_new)) &&
-                       chain_step_exact<FWD>(j, hi_r, arow, my_cur, my_sdd);
-    const f64x2 mt_j = record(j)[kMt], mt_n = record(jn)[kMt];
+    const double chain_next = y_out;                     // what the chain fed to step k+1
+    const bool bits_equal = __double_as_longlong(chain_next) == __double_as_longlong(my_new);
+    const bool bad = chain_step_bad<FWD>(ops, wl / L::PARTS, hi_r, arow, my_cur, my_sdd);
     const int t_j = __double2loint(mt_j.y), t_n = __double2loint(mt_n.y);
     const double m_j = mt_j.x, m_n = mt_n.x;
-    const double nxt = sd2[jn];
-    const bool riding = is_tiny(my_cur - m_j) && (t_j & kBndTrajectory) && (t_n & kBndTrajectory);
-    const bool special = riding || (!isnan(nxt) && (nxt < my_new)) || (my_new > m_n) || (my_new < 0) ||
+    const bool riding = is_tiny(my_cur - m_j) & ((t_j & kBndTrajectory) != 0) & ((t_n & kBndTrajectory) != 0);
+    const bool special = riding | (!isnan(nxt) & (nxt < my_new)) | (my_new > m_n) | (my_new < 0) |
                          isnan(my_new);
-    const bool ok = in_loop && exact && !special;
-    const unsigned long long okm = __ballot(ok);
-    const unsigned long long miss = ~okm & L::kPart0;   // part-0 lanes
+    // a step stands if none of its lanes objects: one ballot, folded over the lanes of a step
+    unsigned long long fm = __ballot(bad | !in_loop | !bits_equal | special);
+    if (G >= 2) fm |= fm >> 1;
+    if (G >= 4) fm |= fm >> 2;
+    const unsigned long long miss = fm & L::kPart0;     // bit 4k: step k failed
     const int Lc = miss ? ((__ffsll((long long)miss) - 1) / G) : K;
     if (Lc == 0) return 0;
     if ((lane & (G - 1)) == 0 && k < Lc) {
