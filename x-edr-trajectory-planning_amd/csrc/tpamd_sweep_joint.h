@@ -1883,40 +1883,31 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     TPAMD_ACC(16, t_a);
     TPAMD_T0(t_b);
     if (w == 0) {
-      // (b) the time integral, strictly left to right (.cc:453-454): one dependent add per
-      //     sample, every lane the same arithmetic, in place
+      // (b) the time integral, strictly left to right (.cc:453-454), 64 samples at a time as a
+      //     pipeline over the lanes: lane L holds dt of sample L of the block; in every round each
+      //     lane adds its dt to the value in front of it and passes the sum one lane up (DPP
+      //     wave_shr:1). Lane 0's input is the running time and never changes, so after round L
+      //     lane L's sum is ((t + dt_0) + dt_1) ... + dt_L, the reference's order of additions,
+      //     and stays that. One add and one 64-bit lane shift per sample, nothing through LDS.
       double t = tprev;
-      f64x2 *tl2 = reinterpret_cast<f64x2 *>(tl);
-      int k = 0;
-      constexpr int kBlk = 8;           // pairs per block; the next block's loads are issued
-                                        // before the adds of the current one
-      f64x2 d[kBlk], dn[kBlk];
-      if (2 * kBlk <= n) {
+      for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + lane;
+        const double dtv = (k < n) ? tl[k] : 0.0;   // (+0.0 past the end: the sum passes through)
+        double x = t, y = 0.0;
 #pragma unroll
-        for (int i = 0; i < kBlk; i++) d[i] = tl2[i];
-      }
-      for (; k + 2 * kBlk <= n; k += 2 * kBlk) {
-        const bool more = k + 4 * kBlk <= n;
-        if (more) {
-#pragma unroll
-          for (int i = 0; i < kBlk; i++) dn[i] = tl2[(k >> 1) + kBlk + i];
+        for (int r = 0; r < 64; r++) {
+          y = x + dtv;
+          if (r < 63) {
+            int lo = __double2loint(x), hi = __double2hiint(x);
+            lo = __builtin_amdgcn_update_dpp(lo, __double2loint(y), 0x138, 0xf, 0xf, false);
+            hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(y), 0x138, 0xf, 0xf, false);
+            x = __hiloint2double(hi, lo);
+          }
         }
-#pragma unroll
-        for (int i = 0; i < kBlk; i++) {
-          t = t + d[i].x; d[i].x = t;
-          t = t + d[i].y; d[i].y = t;
-        }
-        if (lane == 0) {
-#pragma unroll
-          for (int i = 0; i < kBlk; i++) tl2[(k >> 1) + i] = d[i];
-        }
-#pragma unroll
-        for (int i = 0; i < kBlk; i++) d[i] = dn[i];
+        if (k < n) tl[k] = y;
+        t = readlane_f64(y, 63);
       }
-      for (; k < n; k++) {
-        t = t + tl[k];
-        if (lane == 0) tl[k] = t;
-      }
+      JS::wave_lds_sync();
       tprev = t;
     } else {
       // (b') wave 1 meanwhile
