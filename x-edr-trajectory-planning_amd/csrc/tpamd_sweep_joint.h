@@ -47,12 +47,25 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// (bound_ctrl with a zero "old": every lane is written, so the destination needs no copy of the
+// source first -- two moves per value instead of four. A lane whose source lies outside the
+// wave (the ends of a wave shift) reads 0.)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
+}
+
+// max / min of two values that are never NaN: the bare instruction (fmax/fmin would first
+// canonicalise both operands under IEEE mode, doubling the cost of every reduction level).
+template <bool MAX>
+__device__ __forceinline__ double ext2_raw(double a, double b) {
+  double r;
+  if (MAX) asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // Extreme value over each 16-lane DPP row (butterfly: xor 1, xor 2, half-row
@@ -60,10 +73,10 @@ __device__ __forceinline__ double dpp_f64(double v) {
 template <bool MAX>
 __device__ __forceinline__ double row16_extreme(double v) {
   double o;
-  o = dpp_f64<0xB1>(v);  v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // quad_perm [1,0,3,2]
-  o = dpp_f64<0x4E>(v);  v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // quad_perm [2,3,0,1]
-  o = dpp_f64<0x141>(v); v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // row_half_mirror
-  o = dpp_f64<0x140>(v); v = MAX ? __builtin_fmax(o, v) : __builtin_fmin(o, v);   // row_mirror
+  o = dpp_f64<0xB1>(v);  v = ext2_raw<MAX>(o, v);   // quad_perm [1,0,3,2]
+  o = dpp_f64<0x4E>(v);  v = ext2_raw<MAX>(o, v);   // quad_perm [2,3,0,1]
+  o = dpp_f64<0x141>(v); v = ext2_raw<MAX>(o, v);   // row_half_mirror
+  o = dpp_f64<0x140>(v); v = ext2_raw<MAX>(o, v);   // row_mirror
   return v;
 }
 
@@ -153,7 +166,7 @@ struct JointLayout {
 
 template <bool MAX>
 __device__ __forceinline__ double ext2(double a, double b) {
-  return MAX ? __builtin_fmax(a, b) : __builtin_fmin(a, b);
+  return ext2_raw<MAX>(a, b);
 }
 
 // E: extra rows with A = 0 and an explicit B (Cartesian paths: 2, stored as one pair after
@@ -406,9 +419,16 @@ struct JointSweep {
     if (L::PARTS < 4) best = ext2<MAX>(best, dpp_f64<0x4E>(best));
     best = ext2<MAX>(best, dpp_f64<0x141>(best));                      // row_half_mirror
     best = ext2<MAX>(best, dpp_f64<0x140>(best));                      // row_mirror
-    double res = readlane_f64(best, 0);
+    // across the 16-lane rows: every lane folds each row's value (a scalar operand) into its own
+    double res = best;
 #pragma unroll
-    for (int k = 1; k < L::kRows16; k++) res = ext2<MAX>(res, readlane_f64(best, 16 * k));
+    for (int k = 0; k < L::kRows16; k++) {
+      const double rowv = readlane_f64(best, 16 * k);
+      // (s_nop: a scalar register written by v_readlane needs two wait states before a vector
+      // instruction reads it, and the compiler does not look into asm operands for that)
+      if (MAX) asm("s_nop 1\n\tv_max_f64 %0, %1, %2" : "=v"(res) : "v"(res), "s"(rowv));
+      else asm("s_nop 1\n\tv_min_f64 %0, %1, %2" : "=v"(res) : "v"(res), "s"(rowv));
+    }
     const unsigned long long holders = __ballot(mine == res);
     win = __ffsll((long long)holders) - 1;
     if (res == kSentinel) { res = 0; win = -1; }
