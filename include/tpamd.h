@@ -374,7 +374,7 @@ int tpamd_debug_copy_boundary(tpamd_engine *engine, int num_paths, int num_sampl
 void tpamd_debug_keep_boundary(tpamd_engine *engine, int on);
 
 /* Diagnostic builds (-DTPAMD_DIAG) only: per-path counters of the specialised sweep kernel,
- * [B][48] int64: slots 0..23 of the backward wave, 24..47 of the forward wave (meaning of a
+ * [B][64] int64: slots 0..31 of the backward wave, 32..63 of the forward wave (meaning of a
  * slot: csrc/tpamd_sweep_joint.h, JointSweep::diag). The product build leaves them zero. */
 int tpamd_debug_copy_diag(tpamd_engine *engine, int num_paths, long long *out);
 

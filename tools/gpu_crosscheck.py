@@ -31,6 +31,6 @@ for kind, D, N, B in (("joint", 7, 2000, 256), ("joint", 6, 777, 64), ("joint", 
     torch.cuda.synchronize()
     d = E.debug_diag(B)
     report["searches"] += int(d[:, 11].sum())
-    report["mismatches"] += int(d[:, 7].sum() + d[:, 24 + 7].sum())   # both waves run the check
+    report["mismatches"] += int(d[:, 7].sum() + d[:, 32 + 7].sum())   # both waves run the check
     report["cases"].append([kind, D, N, B, int((out["status"] == 0).sum())])
 print(json.dumps(report))

@@ -22,12 +22,12 @@ names = ["extremal cycles (loop)", "wait for partner (loop end)", "crit search",
          "first pair cycles", "scalar FindSdd steps", "loops", "tile fills", "fills w/o prefetch",
          "chain steps accepted", "whole kernel after set-up", "tail: sd/dt pass",
          "tail: time integral | lei+remaining qd/qdd", "literal crit walk (diag only)",
-         "boundary: flags loaded (cum.)", "boundary: +zfit (cum.)", "boundary: +detect (cum.)", "boundary: +final (cum.)", "boundary: final re-fit cycles"]
+         "boundary: flags loaded (cum.)", "boundary: +zfit (cum.)", "boundary: +detect (cum.)", "boundary: +final (cum.)", "boundary: final re-fit cycles", "scalar-step cycles", "boundary-follow cycles", "init_carry cycles", "tile fills", "tile-fill cycles", "init_carry calls"]
 names[12] = "qd/qdd inside the loop"
 names[13] = "tail: up to the sd/dt pass"
 print("%-30s %38s | %38s" % ("B=%d D=%d N=%d" % (B, D, N), "backward wave (mean/min/max)", "forward wave (mean/min/max)"))
 for k, n in enumerate(names):
-    a, f = d[:, k], d[:, 24 + k]
+    a, f = d[:, k], d[:, 32 + k]
     print("%-30s %12.0f %12.0f %12.0f | %12.0f %12.0f %12.0f" % (n, a.mean(), a.min(), a.max(), f.mean(), f.min(), f.max()))
 net = d[:, 15] - d[:, 18]
 print("whole kernel minus the literal walk (backward wave): mean %.0f min %.0f max %.0f" % (net.mean(), net.min(), net.max()))

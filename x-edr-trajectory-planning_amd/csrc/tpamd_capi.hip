@@ -128,7 +128,7 @@ size_t carve_workspace(char *base, int B, int N, int C, Workspace *ws) {
   w.Y = (double *)take(ns * 8);
   w.type = (uint8_t *)take(ns);
   w.sd2 = (double *)take(ns * 8);
-  w.diag = (long long *)take(nb * 48 * 8);
+  w.diag = (long long *)take(nb * 64 * 8);
   if (ws) *ws = w;
   return off;
 }
@@ -1407,7 +1407,7 @@ int tpamd_debug_copy_diag(tpamd_engine *e, int B, long long *out) {
   if (!e || !out || B != e->last_B) return TPAMD_E_INVALID_ARGUMENT;
   TPAMD_ON_DEVICE(e);
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out, e->ws.diag, (size_t)B * 48 * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, e->ws.diag, (size_t)B * 64 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -41,7 +41,7 @@ struct Workspace {
   double *m, *X, *Y;  // final boundary
   uint8_t *type;
   double *sd2;
-  long long *diag;  // [B][16] cycle counters; filled only by -DTPAMD_DIAG builds
+  long long *diag;  // [B][64] cycle counters; filled only by -DTPAMD_DIAG builds
   double *sd2_out;  // optional caller copy of sd2 ([B][N]); may be null
   int keep_boundary;  // the fused boundary passes also store sdd_max/sdd_min/type (debug copy)
 };

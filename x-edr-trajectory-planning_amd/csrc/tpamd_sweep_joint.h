@@ -80,6 +80,61 @@ __device__ __forceinline__ double row16_extreme(double v) {
   return v;
 }
 
+// ---------------------------------------------------------------------------------------
+// Ordered sum of 64 values, one per lane: lane L returns ((t + d_0) + d_1) ... + d_L, the
+// additions in exactly that order (time_optimal_path_timing.cc:453-454 sums left to right).
+// One instruction per value: v_fmac_f64 with a DPP row_newbcast operand computes
+// acc = d[lane c of the row] * 1.0 + acc -- one rounding, the sum's -- in every enabled lane of
+// the row, and EXEC loses one lane per value so that lane c keeps the sum through its own value
+// (a lane never sees a later value, so an infinite increment leaves the earlier sums finite).
+// Rows are chained through row_bcast:15. (tools/micro/chain_bench.hip: 14 cycles per value with
+// two waves per SIMD, against 23 for an add plus a 64-bit lane shift per value.)
+// ---------------------------------------------------------------------------------------
+#define TPAMD_OS_STEP(HALF, C)                                                            \
+  "s_mov_b32 exec_" HALF ", %[m" #C "]\n\t"                                               \
+  "v_fmac_f64_dpp %[acc], %[d], %[one] row_newbcast:" #C " row_mask:0xf bank_mask:0xf\n\t"
+#define TPAMD_OS_ROW(HALF, OTHER)                                                                      \
+  asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b32 exec_" OTHER ", 0\n\t"                              \
+               TPAMD_OS_STEP(HALF, 0) TPAMD_OS_STEP(HALF, 1) TPAMD_OS_STEP(HALF, 2) TPAMD_OS_STEP(HALF, 3)     \
+               TPAMD_OS_STEP(HALF, 4) TPAMD_OS_STEP(HALF, 5) TPAMD_OS_STEP(HALF, 6) TPAMD_OS_STEP(HALF, 7)     \
+               TPAMD_OS_STEP(HALF, 8) TPAMD_OS_STEP(HALF, 9) TPAMD_OS_STEP(HALF, 10) TPAMD_OS_STEP(HALF, 11)   \
+               TPAMD_OS_STEP(HALF, 12) TPAMD_OS_STEP(HALF, 13) TPAMD_OS_STEP(HALF, 14) TPAMD_OS_STEP(HALF, 15) \
+               "s_mov_b64 exec, %[sv]\n\t"                                                             \
+               : [acc] "+v"(acc), [sv] "=&s"(save)                                                     \
+               : [d] "v"(d), [one] "v"(one), TPAMD_OS_M(0), TPAMD_OS_M(1), TPAMD_OS_M(2), TPAMD_OS_M(3), \
+                 TPAMD_OS_M(4), TPAMD_OS_M(5), TPAMD_OS_M(6), TPAMD_OS_M(7), TPAMD_OS_M(8), TPAMD_OS_M(9), \
+                 TPAMD_OS_M(10), TPAMD_OS_M(11), TPAMD_OS_M(12), TPAMD_OS_M(13), TPAMD_OS_M(14), TPAMD_OS_M(15))
+// lanes c..15 of 16-lane row ROW add value c of that row
+template <int ROW>
+__device__ __forceinline__ void ordered_sum_row(double &acc, double d, double one) {
+  constexpr unsigned SH = (ROW & 1) ? 16u : 0u;
+#define TPAMD_OS_M(C) [m##C] "n"((int)(((0xffffu << C) & 0xffffu) << SH))
+  unsigned long long save;
+  if (ROW < 2) TPAMD_OS_ROW("lo", "hi");
+  else TPAMD_OS_ROW("hi", "lo");
+#undef TPAMD_OS_M
+}
+// lane 15 of row ROW-1 to every lane of row ROW
+template <int ROW>
+__device__ __forceinline__ void ordered_sum_carry(double &acc) {
+  int lo = __double2loint(acc), hi = __double2hiint(acc);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x142, 1 << ROW, 0xf, false);   // row_bcast:15
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x142, 1 << ROW, 0xf, false);
+  acc = __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ordered_sum64(double t, double d) {
+  double acc = t;
+  const double one = 1.0;
+  ordered_sum_row<0>(acc, d, one);
+  ordered_sum_carry<1>(acc);
+  ordered_sum_row<1>(acc, d, one);
+  ordered_sum_carry<2>(acc);
+  ordered_sum_row<2>(acc, d, one);
+  ordered_sum_carry<3>(acc);
+  ordered_sum_row<3>(acc, d, one);
+  return acc;
+}
+
 // Diagnostic build only (-DTPAMD_DIAG): per-path cycle counters written to ws.diag;
 // the product build contains none of this.
 #ifdef TPAMD_DIAG
@@ -191,7 +246,9 @@ struct JointSweep {
   // isolated points, deferred fixes, final values + classification), 23 re-fits of the final
   // pass. During the boundary passes 10 / 11 count the re-fits of the final / the first pass
   // (the sweep then counts on top: scalar FindSdd steps / loops).
-  long long diag[24];
+  // 24 scalar-step cycles, 25 boundary-follow cycles, 26 init_carry cycles, 27 tile fills, 28 tile-fill
+  // cycles, 29 init_carry calls
+  long long diag[32];
 #endif
   int N, lane;
   double ds, two_ds;
@@ -279,6 +336,8 @@ struct JointSweep {
   }
   // Make tile t resident; dir tells which neighbour tile to prefetch afterwards.
   __device__ __forceinline__ void fill_tile(int t, int dir, Prefetch &pf) {
+    TPAMD_T0(tf_);
+    TPAMD_CNT(27);
     if (pf.tag != t) issue_tile_loads(t, pf);
     wave_lds_sync();                 // earlier readers of this slot are done
     store_tile(t & 1, pf);           // waits for the loads, writes LDS
@@ -286,6 +345,7 @@ struct JointSweep {
     const int tn = t + dir;
     pf.tag = -1;
     if (tn >= 0 && tn * kTileSamples < N) issue_tile_loads(tn, pf);
+    TPAMD_ACC(28, tf_);
   }
   __device__ __forceinline__ void ensure_tile(int idx, int dir, Prefetch &pf) {
     const int t = idx / kTileSamples;
@@ -560,9 +620,15 @@ struct JointSweep {
   // One step of AddForwardExtremal (.cc:774-855) / AddBackwardExtremal (.cc:864-950): uses
   // the rows in `use`, stages the next step's rows into `stage`. Returns kContinue or the
   // extremal's return value. pair_signal: see add_extremal.
+  // pair_wait (two-wave kernel, first step of a forward extremal): the partner's backward
+  // extremal of the same switching point is running its first step, the only one that touches
+  // samples this extremal touches: it may write sd2[icrit-1] and sdd[icrit] and may read
+  // sd2[icrit+1] (see add_extremal). This step therefore runs up to the point where it would
+  // write (sd2[icrit+1], sdd[icrit]) or read sd2[icrit-1] (intersection, negative sd2) and takes
+  // the partner's release barrier there, not before it starts: the two first steps overlap.
   template <bool FWD>
   __device__ __forceinline__ int extremal_step(Carry &c, const Rows &use, Rows &stage, Prefetch &pf,
-                                               int idx_start, bool &pair_signal) {
+                                               int idx_start, bool &pair_signal, bool &pair_wait) {
     constexpr int dir = FWD ? 1 : -1;
 #define TPAMD_PAIR_SIGNAL()                                   \
   do {                                                        \
@@ -570,6 +636,13 @@ struct JointSweep {
       __threadfence_block();                                  \
       __syncthreads();                                        \
       pair_signal = false;                                    \
+    }                                                         \
+  } while (0)
+#define TPAMD_PAIR_WAIT()                                     \
+  do {                                                        \
+    if (FWD && pair_wait) {                                   \
+      __syncthreads();                                        \
+      pair_wait = false;                                      \
     }                                                         \
   } while (0)
     const int idx = c.idx;
@@ -599,6 +672,7 @@ struct JointSweep {
       sd2tmp = FWD ? cur + two_ds * sddtmp : cur - two_ds * sddtmp;
     }
     if (!isnan(nxt) && (nxt < sd2tmp)) {
+      TPAMD_PAIR_WAIT();
       sdd_at_intersection(idx);
       TPAMD_PAIR_SIGNAL();
       return FWD ? N - 1 : 0;
@@ -612,6 +686,7 @@ struct JointSweep {
       if (stop) {
         end_idx = idx;
         TPAMD_PAIR_SIGNAL();
+        TPAMD_PAIR_WAIT();
         return idx;
       }
       sd2tmp = m_n;
@@ -619,6 +694,7 @@ struct JointSweep {
       c.win = -1;
     }
     if (sd2tmp < 0) {
+      TPAMD_PAIR_WAIT();
       c.win = -1;
       sd2tmp = 0.0;
       if (FWD) {
@@ -627,6 +703,7 @@ struct JointSweep {
         if (idx < N - 1) sddtmp = sd2[idx + 1] / ds; else sddtmp = 0.0;
       }
     }
+    TPAMD_PAIR_WAIT();
     put_sd2(nidx, sd2tmp);
     put_sdd(idx, sddtmp);
     if (!more) end_idx = nidx;
@@ -641,6 +718,7 @@ struct JointSweep {
     c.nxt = uniform_f64(nxt_nn);
     return kContinue;
 #undef TPAMD_PAIR_SIGNAL
+#undef TPAMD_PAIR_WAIT
   }
 
   // Boundary following, 64 steps at a time. While an extremal rides the boundary curve
@@ -798,6 +876,8 @@ struct JointSweep {
   template <bool FWD>
   __device__ __forceinline__ void init_carry(int idx, Carry &c, Rows &rows, Prefetch &pf, bool load_cur) {
     constexpr int dir = FWD ? 1 : -1;
+    TPAMD_T0(ti_);
+    TPAMD_CNT(29);
     c.idx = idx;
     ensure_tile(idx, dir, pf);
     ensure_tile(idx + dir, dir, pf);
@@ -811,6 +891,7 @@ struct JointSweep {
     c.t_i = uniform_i32(t0); c.t_n = uniform_i32(t1);
     c.nxt = uniform_f64(sd2[idx + dir]);
     c.win = -1;
+    TPAMD_ACC(26, ti_);
   }
 
   // AddForwardExtremal (.cc:769-857) for FWD, AddBackwardExtremal (.cc:859-952) otherwise.
@@ -843,13 +924,20 @@ struct JointSweep {
     Rows rows_a, rows_b;
     Carry c;
     init_carry<FWD>(idx_start, c, rows_a, pf, true);
-    if (wait_pair) __syncthreads();
+    // An extremal that starts on the boundary curve writes a whole run at once: wait first. Else
+    // the first step takes the barrier itself, as late as it can (extremal_step).
+    if (wait_pair && is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {
+      __syncthreads();
+      wait_pair = false;
+    }
     bool trust = true;
     int last_win = -1;
     for (;;) {
 #define TPAMD_TRY_FOLLOW()                                                                   \
   if (is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {      \
+    TPAMD_T0(tfb_);                                                                          \
     const int run = uniform_i32(follow_boundary<FWD>(c));                                    \
+    TPAMD_ACC(25, tfb_);                                                                     \
     if (run > 0) {                                                                           \
       TPAMD_CNT(8);                                                                          \
       TPAMD_PAIR_SIGNAL();                                                                   \
@@ -887,7 +975,9 @@ struct JointSweep {
     last_win = c.win;                                                                        \
   }
       TPAMD_TRY_FOLLOW();
-      int r = extremal_step<FWD>(c, rows_a, rows_b, pf, idx_start, pair_signal);
+      TPAMD_T0(ts1_);
+      int r = extremal_step<FWD>(c, rows_a, rows_b, pf, idx_start, pair_signal, wait_pair);
+      TPAMD_ACC(24, ts1_);
       if (r != kContinue) return r;
       TPAMD_TRY_CHAIN();
       if (is_tiny(c.cur - c.m_i) && (c.t_i & kBndTrajectory) && (c.t_n & kBndTrajectory)) {
@@ -895,7 +985,9 @@ struct JointSweep {
         load_rows(c.idx, rows_a);
         continue;
       }
-      r = extremal_step<FWD>(c, rows_b, rows_a, pf, idx_start, pair_signal);
+      TPAMD_T0(ts2_);
+      r = extremal_step<FWD>(c, rows_b, rows_a, pf, idx_start, pair_signal, wait_pair);
+      TPAMD_ACC(24, ts2_);
       if (r != kContinue) return r;
       TPAMD_TRY_CHAIN();
     }
@@ -1562,8 +1654,8 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   double *sd2 = S.sd2;
   const double sd_start = ws.sd_start[b];
 #ifdef TPAMD_DIAG
-  long long(&diag)[24] = S.diag;
-  for (int k = 0; k < 24; k++) diag[k] = 0;
+  long long(&diag)[32] = S.diag;
+  for (int k = 0; k < 32; k++) diag[k] = 0;
 #define TPAMD_DIAG_PTR S.diag
 #else
 #define TPAMD_DIAG_PTR nullptr
@@ -1849,7 +1941,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     }
 #ifdef TPAMD_DIAG
     if (lane == 0 && ws.diag)
-      for (int k = 0; k < 24; k++) ws.diag[(size_t)b * 48 + 24 * w + k] = S.diag[k];
+      for (int k = 0; k < 32; k++) ws.diag[(size_t)b * 64 + 32 * w + k] = S.diag[k];
 #endif
     return;
   }
@@ -1903,27 +1995,15 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     TPAMD_ACC(16, t_a);
     TPAMD_T0(t_b);
     if (w == 0) {
-      // (b) the time integral, strictly left to right (.cc:453-454), 64 samples at a time as a
-      //     pipeline over the lanes: lane L holds dt of sample L of the block; in every round each
-      //     lane adds its dt to the value in front of it and passes the sum one lane up (DPP
-      //     wave_shr:1). Lane 0's input is the running time and never changes, so after round L
-      //     lane L's sum is ((t + dt_0) + dt_1) ... + dt_L, the reference's order of additions,
-      //     and stays that. One add and one 64-bit lane shift per sample, nothing through LDS.
+      // (b) the time integral, strictly left to right (.cc:453-454), 64 samples at a time: lane L
+      //     holds dt of sample L of the block and receives ((t + dt_0) + dt_1) ... + dt_L, the
+      //     reference's order of additions, from ordered_sum64 -- one instruction per sample,
+      //     nothing through LDS.
       double t = tprev;
       for (int k0 = 0; k0 < n; k0 += 64) {
         const int k = k0 + lane;
         const double dtv = (k < n) ? tl[k] : 0.0;   // (+0.0 past the end: the sum passes through)
-        double x = t, y = 0.0;
-#pragma unroll
-        for (int r = 0; r < 64; r++) {
-          y = x + dtv;
-          if (r < 63) {
-            int lo = __double2loint(x), hi = __double2hiint(x);
-            lo = __builtin_amdgcn_update_dpp(lo, __double2loint(y), 0x138, 0xf, 0xf, false);
-            hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(y), 0x138, 0xf, 0xf, false);
-            x = __hiloint2double(hi, lo);
-          }
-        }
+        const double y = ordered_sum64(t, dtv);
         if (k < n) tl[k] = y;
         t = readlane_f64(y, 63);
       }
@@ -2038,7 +2118,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   TPAMD_ACC(15, t_all);
 #ifdef TPAMD_DIAG
   if (lane == 0 && ws.diag)
-    for (int k = 0; k < 24; k++) ws.diag[(size_t)b * 48 + 24 * w + k] = S.diag[k];
+    for (int k = 0; k < 32; k++) ws.diag[(size_t)b * 64 + 32 * w + k] = S.diag[k];
 #endif
 }
 

@@ -427,7 +427,7 @@ class Engine:
         self._lib.tpamd_debug_keep_boundary(self._h, 1 if on else 0)
 
     def debug_diag(self, B):
-        out = np.zeros((B, 48), dtype=np.int64)
+        out = np.zeros((B, 64), dtype=np.int64)
         _check(self._lib.tpamd_debug_copy_diag(self._h, B, _ptr(out)), "tpamd_debug_copy_diag")
         return out
 
