@@ -135,6 +135,49 @@ __device__ __forceinline__ double ordered_sum64(double t, double d) {
   return acc;
 }
 
+// The same sum without touching EXEC, for FINITE values d >= 0: every lane of the row takes part
+// in all sixteen steps, but multiplies the values after its own by 0.0 instead of 1.0 --
+// acc = d_c * m + acc with m = 1.0 for lanes c..15, 0.0 below; d_c * 0.0 = +0.0 and acc + 0.0 = acc
+// exactly (acc is never -0.0 after its first addition of a value >= +0.0). That leaves the bare
+// chain of sixteen dependent v_fmac_f64 per row. The DPP row mask confines a pass to its row.
+// Not for infinite or NaN values (inf * 0.0): the caller checks and falls back to ordered_sum64.
+struct OrderedSumMasks {
+  double m[15];   // m[c-1]: 1.0 in lanes whose position in the row is >= c, else 0.0 (c = 1..15)
+  __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+    for (int c = 1; c < 16; c++) m[c - 1] = ((lane & 15) >= c) ? 1.0 : 0.0;
+  }
+};
+#define TPAMD_OSM_STEP(C, ROWMASK)                                                                    \
+  "v_fmac_f64_dpp %[acc], %[d], %[m" #C "] row_newbcast:" #C " row_mask:" ROWMASK " bank_mask:0xf\n\t"
+#define TPAMD_OSM_ROW(ROWMASK)                                                                          \
+  asm volatile(TPAMD_OSM_STEP(0, ROWMASK) TPAMD_OSM_STEP(1, ROWMASK) TPAMD_OSM_STEP(2, ROWMASK)         \
+               TPAMD_OSM_STEP(3, ROWMASK) TPAMD_OSM_STEP(4, ROWMASK) TPAMD_OSM_STEP(5, ROWMASK)         \
+               TPAMD_OSM_STEP(6, ROWMASK) TPAMD_OSM_STEP(7, ROWMASK) TPAMD_OSM_STEP(8, ROWMASK)         \
+               TPAMD_OSM_STEP(9, ROWMASK) TPAMD_OSM_STEP(10, ROWMASK) TPAMD_OSM_STEP(11, ROWMASK)       \
+               TPAMD_OSM_STEP(12, ROWMASK) TPAMD_OSM_STEP(13, ROWMASK) TPAMD_OSM_STEP(14, ROWMASK)      \
+               TPAMD_OSM_STEP(15, ROWMASK)                                                              \
+               : [acc] "+v"(acc)                                                                        \
+               : [d] "v"(d), [m0] "v"(one), [m1] "v"(k.m[0]), [m2] "v"(k.m[1]), [m3] "v"(k.m[2]),       \
+                 [m4] "v"(k.m[3]), [m5] "v"(k.m[4]), [m6] "v"(k.m[5]), [m7] "v"(k.m[6]), [m8] "v"(k.m[7]), \
+                 [m9] "v"(k.m[8]), [m10] "v"(k.m[9]), [m11] "v"(k.m[10]), [m12] "v"(k.m[11]),           \
+                 [m13] "v"(k.m[12]), [m14] "v"(k.m[13]), [m15] "v"(k.m[14]))
+__device__ __forceinline__ double ordered_sum64_finite(double t, double d, const OrderedSumMasks &k) {
+  double acc = t;
+  const double one = 1.0;
+  // (the value d may have been written by the instruction just before: a DPP operand needs two
+  // wait states after a VALU write, which the compiler cannot see inside the asm)
+  asm volatile("s_nop 1" ::: "memory");
+  TPAMD_OSM_ROW("0x1");
+  ordered_sum_carry<1>(acc);
+  TPAMD_OSM_ROW("0x2");
+  ordered_sum_carry<2>(acc);
+  TPAMD_OSM_ROW("0x4");
+  ordered_sum_carry<3>(acc);
+  TPAMD_OSM_ROW("0x8");
+  return acc;
+}
+
 // Diagnostic build only (-DTPAMD_DIAG): per-path cycle counters written to ws.diag;
 // the product build contains none of this.
 #ifdef TPAMD_DIAG
@@ -400,42 +443,54 @@ struct JointSweep {
       qdd_g[o] = acc;
     }
   }
-  // Samples lo..hi (inclusive) from the current sd2 (LDS), sdd and records (global); one thread
-  // per (sample, joint), consecutive threads store consecutive addresses; four passes in
-  // flight. `t` of `nthreads` threads take part (one wave: lane of 64; the workgroup: tid of 128).
-  // stop != nullptr: give up as soon as *stop == stop_value (checked between batches) -- the
+  // Samples lo..hi (inclusive) from the current sd2 (LDS), sdd and records (global), 64 samples
+  // per trip of a wave: lane l first takes sample s0 + l -- sd = sqrt(sd2) and sdd once per sample,
+  // one coalesced load -- then the trip's 64*D (sample, joint) pairs are spread over D passes of
+  // 64 lanes, consecutive lanes storing consecutive addresses, every lane fetching its sample's sd
+  // and sdd from the lane that holds them (ds_bpermute: the LDS crossbar, no LDS memory). All
+  // loads of a trip are issued before its arithmetic. Wave `wv` of `nwv` waves takes every nwv-th
+  // trip (one wave: 0 of 1; the workgroup: tid >> 6 of 2).
+  // stop != nullptr: give up as soon as *stop == stop_value (checked between trips) -- the
   // partner wave has finished and must not be kept waiting. Returns the first sample NOT
   // written (hi + 1 if the range was completed).
-  __device__ __forceinline__ int emit_range(int lo, int hi, int t, int nthreads,
+  __device__ __forceinline__ int emit_range(int lo, int hi, int wv, int nwv,
                                             const volatile int *stop = nullptr,
                                             int stop_value = 0) const {
     if (!emitting() || hi < lo) return hi + 1;
     const f64x2 *rec2 = reinterpret_cast<const f64x2 *>(rec);
-    const int total = (hi - lo + 1) * D;
-#ifndef TPAMD_EMIT_UNROLL
-#define TPAMD_EMIT_UNROLL 8
-#endif
-    constexpr int U = TPAMD_EMIT_UNROLL;
-    for (int b0 = 0; b0 < total; b0 += nthreads * U) {
-      if (stop != nullptr && *stop == stop_value) return lo + b0 / D;   // (uniform)
-      const int e0 = b0 + t;
-      f64x2 pr[U];
-      double s2[U], a[U], amx[U];
-      int ii[U], dd[U];
+    for (int s0 = lo + 64 * wv; s0 <= hi; s0 += 64 * nwv) {
+      if (stop != nullptr && *stop == stop_value) return s0;                // (uniform)
+      const int cnt = min(64, hi - s0 + 1);                                  // samples of this trip
+      const int mine = s0 + min(lane, cnt - 1);
+      const double s2l = sd2[mine];
+      const double al = sdd_g[mine];
+      const double vl = sqrt(s2l);
+      constexpr int G = (D <= 8) ? D : 7;                                    // passes in flight
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int e = min(e0 + nthreads * u, total - 1);
-        const int se = e / D;
-        ii[u] = lo + se;
-        dd[u] = e - se * D;
-        pr[u] = rec2[(size_t)ii[u] * (R / 2) + dd[u]];
-        s2[u] = sd2[ii[u]];
-        a[u] = sdd_g[ii[u]];
-        amx[u] = aml[dd[u]];
+      for (int u0 = 0; u0 < D; u0 += G) {
+        f64x2 pr[G];
+        double amx[G];
+        int se[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          const int e = min(64 * (u0 + g) + lane, cnt * D - 1);
+          se[g] = e / D;                                                     // sample within the trip
+          const int dd = e - se[g] * D;
+          pr[g] = rec2[(size_t)(s0 + se[g]) * (R / 2) + dd];
+          amx[g] = aml[dd];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+          if (u0 + g >= D) continue;
+          const int src = se[g] << 2;
+          const double v = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(vl)),
+                                            __builtin_amdgcn_ds_bpermute(src, __double2loint(vl)));
+          const double a = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(al)),
+                                            __builtin_amdgcn_ds_bpermute(src, __double2loint(al)));
+          const int e = 64 * (u0 + g) + lane;
+          if (e < cnt * D) emit_value(s0 + se[g], e - se[g] * D, pr[g], v, a, amx[g]);
+        }
       }
-#pragma unroll
-      for (int u = 0; u < U; u++)
-        if (e0 + nthreads * u < total) emit_value(ii[u], dd[u], pr[u], sqrt(s2[u]), a[u], amx[u]);
     }
     return hi + 1;
   }
@@ -1769,7 +1824,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 #endif
     if (TPAMD_EMIT_IN_LOOP) {
       upper_lo = min(S.end_idx + 3, N);
-      S.emit_range(upper_lo, N - 1, lane, 64);
+      S.emit_range(upper_lo, N - 1, 0, 1);
     }
   }
   __threadfence_block();
@@ -1835,7 +1890,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
         TPAMD_T0(te);
         if (TPAMD_EMIT_IN_LOOP)
           emitted_hi = uniform_i32(S.emit_range(max(min(S.end_idx - 1, emitted_hi), 0), icrit - 1,
-                                                lane, 64, xchg + 6, loop + 1));
+                                                0, 1, xchg + 6, loop + 1));
         TPAMD_ACC(12, te);
       } else {
         const int r = S.template add_extremal<true>(iforw_lo, pf, false, /*wait_pair=*/true);   // B inside
@@ -1952,7 +2007,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     // the first pair, or as far as the connecting forward extremal rewrote that region
     const int e_hi = uniform_i32(xchg[4]), u_lo = uniform_i32(xchg[5]);
     const int f_end = uniform_i32(xchg[3]);
-    S.emit_range(e_hi, min(max(u_lo - 1, f_end + 1), N - 1), tid, 128);
+    S.emit_range(e_hi, min(max(u_lo - 1, f_end + 1), N - 1), w, 2);
   }
   TPAMD_ACC(13, t_tail);
   const double t0v = ws.t_start[b];
@@ -2000,10 +2055,15 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
       //     reference's order of additions, from ordered_sum64 -- one instruction per sample,
       //     nothing through LDS.
       double t = tprev;
+      OrderedSumMasks osm;
+      osm.init(lane);
       for (int k0 = 0; k0 < n; k0 += 64) {
         const int k = k0 + lane;
         const double dtv = (k < n) ? tl[k] : 0.0;   // (+0.0 past the end: the sum passes through)
-        const double y = ordered_sum64(t, dtv);
+        // (increments are >= 0; an infinite one -- both velocities denormal -- takes the variant
+        // that never multiplies)
+        const bool finite = __ballot(!(dtv <= DBL_MAX)) == 0ull;
+        const double y = finite ? ordered_sum64_finite(t, dtv, osm) : ordered_sum64(t, dtv);
         if (k < n) tl[k] = y;
         t = readlane_f64(y, 63);
       }
