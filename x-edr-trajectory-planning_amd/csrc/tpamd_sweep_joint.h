@@ -521,8 +521,9 @@ struct JointSweep {
     bool bad = (fabs(r.own.x) < kTiny) | (sddi != sddi);
 #pragma unroll
     for (int k = 0; k < L::RPL; k++) {
+      // (v + kTiny < -hi) | (v - kTiny > hi) as one comparison, see find_sdd_both_joint_fixed
       const double v = r.chk[k].x * sddi + r.chk[k].y * s2;
-      bad = bad | (v + kTiny < -chk_hi[k]) | (v - kTiny > chk_hi[k]);
+      bad = bad | (fabs(v) - kTiny > chk_hi[k]);
     }
     double best = bad ? kSentinel : sddi;
     const double mine = best;
@@ -588,18 +589,24 @@ struct JointSweep {
 #pragma unroll
     for (int i = 0; i < L::VPL; i++) {       // winner against this lane's share of the rows
       const f64x2 pr = o.pvv[i];
+      // (v + kTiny < -hi) | (v - kTiny > hi) as one comparison, see find_sdd_both_joint_fixed
       const double v = pr.x * sddw + pr.y * s2;
-      bad = bad | (v + kTiny < -va_hi[i]) | (v - kTiny > va_hi[i]);
+      bad = bad | (fabs(v) - kTiny > va_hi[i]);
+      // velocity row: q'^2 sd2 >= 0 here (a step whose sd2 is negative is never accepted: the
+      // step before it is flagged), so only the upper bound can fail
       const double vv = (pr.x * pr.x) * s2;
-      bad = bad | (vv + kTiny < 0.0) | (vv - kTiny > vv_hi[i]);
+      bad = bad | (vv - kTiny > vv_hi[i]);
     }
     if (E > 0) {                              // extra rows (every lane: two cheap checks)
       const double v0 = o.ex.x * s2, v1 = o.ex.y * s2;
-      bad = bad | (v0 + kTiny < -ex_hi[0]) | (v0 - kTiny > ex_hi[0]);
-      bad = bad | (v1 + kTiny < -ex_hi[E - 1]) | (v1 - kTiny > ex_hi[E - 1]);
+      bad = bad | (fabs(v0) - kTiny > ex_hi[0]);
+      bad = bad | (fabs(v1) - kTiny > ex_hi[E - 1]);
     }
     const int p0 = lane & (L::GRP - 1);
-    const double aw = fabs(sddw);
+    // the screens below are comparisons only (never results): fused operations are fine
+    const double better_than = MAX ? sddw - 2e-6 * fabs(sddw) : sddw + 2e-6 * fabs(sddw);
+    const double row_limit = (hi_r + 2.0 * kTiny) * (1.0 + 2e-12);
+    const double bs_r = arow.y * s2;
 #pragma unroll
     for (int i = 0; i < L::CPL; i++) {       // this lane's other candidates
       const f64x2 own = o.pown[i];
@@ -608,11 +615,13 @@ struct JointSweep {
       // speculated candidate itself (equal, hence not better)
       const bool skip = (lim_i != lim_i) | (fabs(own.x) < kTiny) | (p0 + L::GRP * i == win_cand);
       const double sa = (lim_i - own.y * s2) * o.rc[i];
-      const double tol = 2e-6 * fabs(sa) + 1e-300;
-      const bool not_better = MAX ? (sa + tol < sddw - 2e-6 * aw) : (sa - tol > sddw + 2e-6 * aw);
+      // sa -+ 2e-6 |sa| against sddw +- 2e-6 |sddw|
+      const bool not_better = MAX ? (__builtin_fma(2e-6, fabs(sa), sa) < better_than)
+                                  : (__builtin_fma(-2e-6, fabs(sa), sa) > better_than);
+      // |a_r sa + b_r sd2| beyond row r's bound by more than any rounding of either evaluation
       const double ax = arow.x * sa;
-      const double va = ax + arow.y * s2;
-      const bool violates = fabs(va) > hi_r + 2.0 * kTiny + 2e-6 * fabs(ax) + 1e-12 * (fabs(va) + hi_r);
+      const double va = ax + bs_r;
+      const bool violates = __builtin_fma(-2e-6, fabs(ax), fabs(va) * (1.0 - 1e-12)) > row_limit;
       bad = bad | !(skip | not_better | violates);
     }
     return bad;
@@ -893,8 +902,12 @@ struct JointSweep {
         const int ylo = __double2loint(y_out), yhi = __double2hiint(y_out);
         lo = __builtin_amdgcn_update_dpp(lo, ylo, 0x114, 0xf, 0xf, false);    // row_shr:4
         hi = __builtin_amdgcn_update_dpp(hi, yhi, 0x114, 0xf, 0xf, false);
-        lo = __builtin_amdgcn_update_dpp(lo, ylo, 0x142, 0xe, 0x1, false);    // row_bcast:15 -> lanes 0-3 of rows 1-3
-        hi = __builtin_amdgcn_update_dpp(hi, yhi, 0x142, 0xe, 0x1, false);
+        // into the next 16-lane row only when a row's last step has just become final (rounds 3,
+        // 7, 11): lanes 0-3 of a row keep what they have in between
+        if ((s & 3) == 3) {
+          lo = __builtin_amdgcn_update_dpp(lo, ylo, 0x142, 0xe, 0x1, false);  // row_bcast:15 -> lanes 0-3 of rows 1-3
+          hi = __builtin_amdgcn_update_dpp(hi, yhi, 0x142, 0xe, 0x1, false);
+        }
         x = __hiloint2double(hi, lo);
       }
     }
