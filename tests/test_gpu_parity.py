@@ -325,8 +325,8 @@ def test_cartesian_paths_match_oracle(env, D, N, B):
 
 
 def test_engine_reproduces_committed_regression_vectors(env, golden_dir):
-    """The oracle-generated vectors of tests/golden/solver_golden.npz, bit for bit."""
-    stored = dict(np.load(os.path.join(golden_dir, "solver_golden.npz")))
+    """The oracle-generated vectors of tests/golden/solver_oracle_derived.npz, bit for bit."""
+    stored = dict(np.load(os.path.join(golden_dir, "solver_oracle_derived.npz")))
     for name, rows, s0, s1, sd0, _meta in scenarios.all_cases():
         out = _rows_solve(env, [rows], s0, s1, sd0)
         assert out["status"][0] == stored["scn/%s/status" % name][0], name

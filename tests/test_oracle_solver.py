@@ -128,7 +128,7 @@ def test_end_padding_beyond_last_knot():
 
 
 def test_oracle_reproduces_committed_regression_vectors(golden_dir):
-    """tests/golden/solver_golden.npz (tools/make_solver_golden.py): oracle-generated, hence a
+    """tests/golden/solver_oracle_derived.npz (tools/make_solver_golden.py): oracle-generated, hence a
     regression pin of the oracle itself, not a parity pin against the reference."""
     import importlib.util
     import os
@@ -137,7 +137,7 @@ def test_oracle_reproduces_committed_regression_vectors(golden_dir):
                                            "make_solver_golden.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    stored = dict(np.load(os.path.join(golden_dir, "solver_golden.npz")))
+    stored = dict(np.load(os.path.join(golden_dir, "solver_oracle_derived.npz")))
     sha = bytes(stored.pop("sha256")).decode()
     assert mod.digest(stored) == sha, "fixture file corrupted"
     now = mod.compute()

@@ -7,7 +7,7 @@ shows up as a diff against committed data. Problems: the 19 scenario cases of th
 solver tests (tests/scenarios.py) and 8 seeded synthetic joint-spline paths for each of
 (D, N) in {(7,500), (7,2000), (6,2000), (14,1000)}.
 
-  python tools/make_solver_golden.py      -> tests/golden/solver_golden.npz (+ sha256 inside)
+  python tools/make_solver_golden.py      -> tests/golden/solver_oracle_derived.npz (+ sha256 inside)
 """
 import hashlib
 import importlib
@@ -64,6 +64,6 @@ def digest(arrays):
 if __name__ == "__main__":
     arrays = compute()
     arrays["sha256"] = np.frombuffer(digest(arrays).encode(), dtype=np.uint8)
-    path = os.path.join(ROOT, "tests", "golden", "solver_golden.npz")
+    path = os.path.join(ROOT, "tests", "golden", "solver_oracle_derived.npz")
     np.savez_compressed(path, **arrays)
     print(path, os.path.getsize(path), "bytes,", len(arrays) - 1, "arrays")

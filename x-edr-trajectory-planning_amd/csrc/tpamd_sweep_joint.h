@@ -204,7 +204,14 @@ __device__ __forceinline__ long long tpamd_stamp() {
 #ifndef TPAMD_TILE_SAMPLES
 #define TPAMD_TILE_SAMPLES 32
 #endif
-constexpr int kTileSamples = TPAMD_TILE_SAMPLES;
+constexpr int kTileSamples = TPAMD_TILE_SAMPLES;   // largest tile (the engine pads the records by one)
+// Samples per tile of the D-joint sweep: wide records (D > 8: 30 doubles at D = 14) take 16-sample
+// tiles, which halves the prefetch registers and the rings (the 14-joint kernel spilled 288 bytes
+// per lane with 32-sample tiles).
+template <int D>
+struct TileCfg {
+  static constexpr int kSamples = (D > 8 && TPAMD_TILE_SAMPLES > 16) ? 16 : TPAMD_TILE_SAMPLES;
+};
 
 // 16-byte pair as a native vector type: plain loads/stores that the compiler keeps in
 // registers (copies of HIP's f64x2 struct are emitted as memcpy and can pin the
@@ -275,7 +282,8 @@ struct JointSweep {
   static_assert(E == 0 || E == 2, "extra rows come as one pair");
   static constexpr int R = 2 * D + E + 2;                   // doubles per record
   static constexpr int kMt = D + E / 2;                     // pair index of (sd2_max, type)
-  static constexpr int kChunks = kTileSamples * R / 2;      // 16-byte chunks per tile
+  static constexpr int kTile = TileCfg<D>::kSamples;        // samples per tile
+  static constexpr int kChunks = kTile * R / 2;             // 16-byte chunks per tile
   static constexpr int kChunksPerLane = (kChunks + 63) / 64;
 #ifdef TPAMD_DIAG
   // per wave: 0 extremal cycles inside the loop, 1 cycles waiting for the partner at the end of
@@ -296,7 +304,7 @@ struct JointSweep {
   int N, lane;
   double ds, two_ds;
   double *sd2;            // LDS [N]
-  double *tiles;          // LDS [2][kTileSamples][R]
+  double *tiles;          // LDS [2][kTile][R]
   const uint8_t *typel;   // LDS [N] copy of the type bytes
   double *sdd_g;          // global: sdd output row of this path
   const double *m_g;      // global: final sd2_max of this path [N]
@@ -355,21 +363,21 @@ struct JointSweep {
   // record: one write transaction per sample).
   struct Prefetch {
     RegPack<kChunksPerLane> r;
-    double m;  // lanes 0..kTileSamples-1: final sd2_max of sample t*kTileSamples + lane
+    double m;  // lanes 0..kTile-1: final sd2_max of sample t*kTile + lane
     int tag;   // tile index held in r (-1: none)
   };
   __device__ __forceinline__ void issue_tile_loads(int t, Prefetch &pf) const {
-    const f64x2 *src = reinterpret_cast<const f64x2 *>(rec + (size_t)t * kTileSamples * R);
+    const f64x2 *src = reinterpret_cast<const f64x2 *>(rec + (size_t)t * kTile * R);
     pf.r.template load<kChunks>(src, lane);
-    pf.m = m_g[min(t * kTileSamples + (lane & (kTileSamples - 1)), N - 1)];
+    pf.m = m_g[min(t * kTile + (lane & (kTile - 1)), N - 1)];
     pf.tag = t;
   }
   __device__ __forceinline__ void store_tile(int slot, const Prefetch &pf) const {
-    f64x2 *dst = reinterpret_cast<f64x2 *>(tiles + (size_t)slot * kTileSamples * R);
+    f64x2 *dst = reinterpret_cast<f64x2 *>(tiles + (size_t)slot * kTile * R);
     pf.r.template store<kChunks>(dst, lane);
     wave_lds_sync();                 // the chunk stores land before the (m, type) pairs
-    if (lane < kTileSamples) {
-      const int i = min(pf.tag * kTileSamples + lane, N - 1);
+    if (lane < kTile) {
+      const int i = min(pf.tag * kTile + lane, N - 1);
       f64x2 mt;
       mt.x = pf.m;
       mt.y = __longlong_as_double((long long)typel[i]);
@@ -387,17 +395,17 @@ struct JointSweep {
     if (t & 1) tag1 = t; else tag0 = t;
     const int tn = t + dir;
     pf.tag = -1;
-    if (tn >= 0 && tn * kTileSamples < N) issue_tile_loads(tn, pf);
+    if (tn >= 0 && tn * kTile < N) issue_tile_loads(tn, pf);
     TPAMD_ACC(28, tf_);
   }
   __device__ __forceinline__ void ensure_tile(int idx, int dir, Prefetch &pf) {
-    const int t = idx / kTileSamples;
+    const int t = idx / kTile;
     const int tag = (t & 1) ? tag1 : tag0;
     if (tag != t) fill_tile(t, dir, pf);
   }
   __device__ __forceinline__ const f64x2 *record(int idx) const {
     // slot = (idx / 32) & 1, position = idx % 32  ==  idx & 63 in a 64-record ring
-    return reinterpret_cast<const f64x2 *>(tiles) + (size_t)(idx & (2 * kTileSamples - 1)) * (R / 2);
+    return reinterpret_cast<const f64x2 *>(tiles) + (size_t)(idx & (2 * kTile - 1)) * (R / 2);
   }
   __device__ __forceinline__ void load_rows(int idx, Rows &r) const {
     const f64x2 *p = record(idx);
@@ -714,7 +722,7 @@ struct JointSweep {
     const bool more = FWD ? (nidx < N - 2) : (nidx > 1);
     // stage the next step's data (1 <= nidx <= N-2, 0 <= nidx+dir <= N-1); a new tile can
     // only be entered at a tile edge
-    if (((nidx + dir) & (kTileSamples - 1)) == (FWD ? 0 : kTileSamples - 1))
+    if (((nidx + dir) & (kTile - 1)) == (FWD ? 0 : kTile - 1))
       ensure_tile(nidx + dir, dir, pf);
     load_rows(nidx, stage);
     double m_nn;
@@ -806,7 +814,7 @@ struct JointSweep {
     // latency); a step whose samples lie beyond them simply ends this call's run -- the caller
     // re-centres the tiles and comes back.
     const int jn = j + dir;
-    const int tj = max(j, 0) / kTileSamples, tjn = max(jn, 0) / kTileSamples;
+    const int tj = max(j, 0) / kTile, tjn = max(jn, 0) / kTile;
     const bool resident = (tj == tag0 || tj == tag1) && (tjn == tag0 || tjn == tag1);
     if (in_loop && j >= 0 && j < N && resident) {
       const f64x2 mt_j = record(j)[kMt], mt_n = record(jn)[kMt];
@@ -1646,7 +1654,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
 template <int D, int E = 0>
 struct SweepLds {
   static constexpr int R = 2 * D + E + 2;
-  static constexpr int kRingDoubles = 2 * 2 * kTileSamples * R;
+  static constexpr int kRingDoubles = 2 * 2 * TileCfg<D>::kSamples * R;
   __host__ __device__ static constexpr int n2(int N) { return (N + 1) & ~1; }
   __host__ __device__ static constexpr int words(int N) { return ((N + 31) / 32 + 1) & ~1; }
   __host__ __device__ static constexpr int type_bytes(int N) { return ((N + 15) / 16) * 16; }
@@ -1701,7 +1709,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   S.two_ds = 2.0 * S.ds;
   S.sd2 = lds;
   double *ring = lds + LL::n2(N);
-  S.tiles = ring + (size_t)w * 2 * kTileSamples * JS::R;
+  S.tiles = ring + (size_t)w * 2 * JS::kTile * JS::R;
   uint8_t *typel = reinterpret_cast<uint8_t *>(ring + LL::kRingDoubles);
   S.typel = typel;
   int *xchg = reinterpret_cast<int *>(typel + LL::type_bytes(N));
@@ -1875,7 +1883,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     if (icrit >= 1) {
       // the tile this wave's extremal starts in: its loads fly together with the loads of
       // the boundary values below instead of after them
-      const int ts = ((w == 1) ? icrit : icrit - 1) / kTileSamples;
+      const int ts = ((w == 1) ? icrit : icrit - 1) / JS::kTile;
       const int tag = (ts & 1) ? S.tag1 : S.tag0;
       if (tag != ts && pf.tag != ts) S.issue_tile_loads(ts, pf);
     }
