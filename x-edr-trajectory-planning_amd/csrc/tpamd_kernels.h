@@ -541,21 +541,19 @@ __global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Work
   double *s_lo = lds, *s_hi = s_lo + C;
   double *s_Q1 = s_hi + C, *s_Q2 = s_Q1 + (size_t)D * TPB, *s_X = s_Q2 + (size_t)D * TPB;
   for (int k = tid; k < 2 * C; k += TPB) s_lo[k] = ws.lim[(size_t)b * 2 * C + k];
-  __syncthreads();
-  const int i = blockIdx.x * TPB + tid;
-  if (i >= N) return;
-  const size_t o = (size_t)b * N + i;
+  const int i0 = blockIdx.x * TPB;
+  const int i = i0 + tid;
+  const bool live = i < N;
+  const size_t o = (size_t)b * N + (live ? i : N - 1);
   const double inv = 1.0 / ws.delta[b];
   const double *q = q_g + o * D;
-  const double *J = J_g + o * 6 * D;
   double *rec = ws.q12 + o * (C + 2);
   double *Q1 = s_Q1 + tid, *Q2 = s_Q2 + tid, *X = s_X + tid;
   double q1r[D], q2r[D];
-  double v6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int d = 0; d < D; d++) {
     double q1 = 0.0, q2 = 0.0;
-    if (i < N - 1) {
+    if (live && i < N - 1) {
       q1 = inv * (q[D + d] - q[d]);
       if (i >= 1) {
         const double q1n = (i + 1 < N - 1) ? inv * (q[2 * D + d] - q[D + d]) : 0.0;
@@ -563,12 +561,51 @@ __global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Work
       }
     }
     q1r[d] = q1; q2r[d] = q2;
-    *reinterpret_cast<double2 *>(rec + 2 * d) = make_double2(q1, q2);
+    if (live) *reinterpret_cast<double2 *>(rec + 2 * d) = make_double2(q1, q2);
     Q1[d * TPB] = q1;
-    Q2[d * TPB] = q2;
-#pragma unroll
-    for (int r = 0; r < 6; r++) v6[r] += J[r * D + d] * q1;
   }
+  __syncthreads();
+  // J q' (timeable_path_cartesian_spline.cc:551-560), one thread per (sample, Cartesian row): the
+  // block's Jacobians are one contiguous run of 6 D doubles per sample, so consecutive threads
+  // read consecutive rows (a thread per sample would stride 48 D bytes: 64 cache lines per load
+  // instruction). Each dot product adds its D terms in the reference's order, starting from 0.
+  // The six results of a sample go back to its owner through the LDS that holds q'' afterwards.
+  {
+    double *V6 = s_Q2;                        // [6][TPB] <= [D][TPB]
+    const int nvalid = min(TPB, N - i0);
+    const double *Jb = J_g + ((size_t)b * N + i0) * 6 * D;
+    for (int p = tid; p < 6 * nvalid; p += TPB) {
+      const int sm = p / 6, r = p - 6 * sm;
+      const double *Jr = Jb + (size_t)p * D;
+      double acc = 0.0;
+      if (D % 2 == 0) {
+        const double2 *J2 = reinterpret_cast<const double2 *>(Jr);
+        double2 jj[D / 2 ? D / 2 : 1];
+#pragma unroll
+        for (int h = 0; h < D / 2; h++) jj[h] = J2[h];
+#pragma unroll
+        for (int h = 0; h < D / 2; h++) {
+          acc += jj[h].x * s_Q1[(2 * h) * TPB + sm];
+          acc += jj[h].y * s_Q1[(2 * h + 1) * TPB + sm];
+        }
+      } else {
+        double jj[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) jj[d] = Jr[d];
+#pragma unroll
+        for (int d = 0; d < D; d++) acc += jj[d] * s_Q1[d * TPB + sm];
+      }
+      V6[r * TPB + sm] = acc;
+    }
+  }
+  __syncthreads();
+  double v6[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) v6[r] = s_Q2[r * TPB + tid];
+  __syncthreads();                            // everyone has its six values: q'' may go there now
+#pragma unroll
+  for (int d = 0; d < D; d++) Q2[d * TPB] = q2r[d];
+  if (!live) return;
   const double bt = (v6[0] * v6[0] + v6[1] * v6[1]) + v6[2] * v6[2];
   const double br = (v6[3] * v6[3] + v6[4] * v6[4]) + v6[5] * v6[5];
   *reinterpret_cast<double2 *>(rec + 2 * D) = make_double2(bt, br);
