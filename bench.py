@@ -316,11 +316,18 @@ def main():
     # load. Untimed, reported in config.clock_warmup_ms.
     if args.clock_warmup_ms > 0:
         t_end = time.perf_counter() + args.clock_warmup_ms * 1e-3
-        while time.perf_counter() < t_end:
+        while True:
             for _ in range(8):
                 step()
             finish()
             torch.cuda.synchronize()
+            go = time.perf_counter() < t_end
+            if distributed:     # every rank must issue the same number of gathers: stop together
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                go = bool(flag.item())
+            if not go:
+                break
     for _ in range(args.warmup):
         step()
     finish()
