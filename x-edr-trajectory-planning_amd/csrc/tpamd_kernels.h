@@ -197,17 +197,20 @@ __global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
   for (int k = tid; k < P * D; k += TPB) s_cp[k] = cps_g[(size_t)b * P * D + k];
   for (int k = tid; k < 2 * C; k += TPB) s_lo[k] = ws.lim[(size_t)b * 2 * C + k];
   __syncthreads();
-  const int i = blockIdx.x * TPB + tid;
-  if (i >= path_samples(ws, b, N)) return;
+  const int i0 = blockIdx.x * TPB;
+  const int i = i0 + tid;
+  const int Nb = path_samples(ws, b, N);
+  const bool live = i < Nb;
   const size_t o = (size_t)b * N + i;
 
   const double path_start = ws.s_start[b];
   const double delta = ws.delta[b];
   const double k0 = s_knots[0], kend = s_knots[K - 1];
   const double parameter = path_start + i * delta;
-  double *q12 = ws.q12 + o * (C + 2);
   double *Q1 = s_Q1 + tid, *Q2 = s_Q2 + tid;
-  if (parameter < kend + delta) {
+  if (!live) {
+    // (stays for the block's record store below)
+  } else if (parameter < kend + delta) {
     double u = parameter;
     if (u < k0) u = k0;
     if (kend < u) u = kend;
@@ -222,7 +225,6 @@ __global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
       v1 += ders[1][0] * p0[d]; v1 += ders[1][1] * p1[d]; v1 += ders[1][2] * p2[d];
       v2 += ders[2][0] * p0[d]; v2 += ders[2][1] * p1[d]; v2 += ders[2][2] * p2[d];
       if (q_out) q_out[o * D + d] = v0;
-      *reinterpret_cast<double2 *>(q12 + 2 * d) = make_double2(v1, v2);
       Q1[d * TPB] = v1;
       Q2[d * TPB] = v2;
       if (DT) { q1r[d] = v1; q2r[d] = v2; }
@@ -232,12 +234,27 @@ __global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
 #pragma unroll
     for (int d = 0; d < D; d++) {
       if (q_out) q_out[o * D + d] = pl[d];
-      *reinterpret_cast<double2 *>(q12 + 2 * d) = make_double2(0.0, 0.0);
       Q1[d * TPB] = 0.0;
       Q2[d * TPB] = 0.0;
       if (DT) { q1r[d] = 0.0; q2r[d] = 0.0; }
     }
   }
+  // The block's records -- [q'_d, q''_d] * D | pad, one contiguous run of (D + 1) 16-byte pairs
+  // per sample -- written by consecutive threads from the LDS columns: whole cache lines per
+  // store instruction (a thread storing its own record touches 64 lines per instruction, and the
+  // partially written lines reach HBM more than once). The pad pair is written too (zeros; the
+  // sweep fills it in its LDS copy only) so that the lines are complete.
+  __syncthreads();
+  {
+    const int nvalid = min(TPB, Nb - i0);
+    double2 *recs = reinterpret_cast<double2 *>(ws.q12 + ((size_t)b * N + i0) * (C + 2));
+    const int pairs = D + 1;
+    for (int c = tid; c < nvalid * pairs; c += TPB) {
+      const int sm = c / pairs, pr = c - sm * pairs;
+      recs[c] = (pr < D) ? make_double2(s_Q1[pr * TPB + sm], s_Q2[pr * TPB + sm]) : make_double2(0.0, 0.0);
+    }
+  }
+  if (!live) return;
   LdsRowsJoint r;
   r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
   if (DT) {
@@ -547,7 +564,6 @@ __global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Work
   const size_t o = (size_t)b * N + (live ? i : N - 1);
   const double inv = 1.0 / ws.delta[b];
   const double *q = q_g + o * D;
-  double *rec = ws.q12 + o * (C + 2);
   double *Q1 = s_Q1 + tid, *Q2 = s_Q2 + tid, *X = s_X + tid;
   double q1r[D], q2r[D];
 #pragma unroll
@@ -561,7 +577,6 @@ __global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Work
       }
     }
     q1r[d] = q1; q2r[d] = q2;
-    if (live) *reinterpret_cast<double2 *>(rec + 2 * d) = make_double2(q1, q2);
     Q1[d * TPB] = q1;
   }
   __syncthreads();
@@ -605,12 +620,26 @@ __global__ void k_cartesian_lp(int N, const double *q_g, const double *J_g, Work
   __syncthreads();                            // everyone has its six values: q'' may go there now
 #pragma unroll
   for (int d = 0; d < D; d++) Q2[d * TPB] = q2r[d];
-  if (!live) return;
   const double bt = (v6[0] * v6[0] + v6[1] * v6[1]) + v6[2] * v6[2];
   const double br = (v6[3] * v6[3] + v6[4] * v6[4]) + v6[5] * v6[5];
-  *reinterpret_cast<double2 *>(rec + 2 * D) = make_double2(bt, br);
   X[0] = bt;
   X[TPB] = br;
+  // the block's records ([q'_d, q''_d] * D | bt, br | pad: D + 2 pairs per sample, contiguous)
+  // written by consecutive threads from the LDS columns, whole cache lines per instruction
+  __syncthreads();
+  {
+    const int nvalid = min(TPB, N - i0);
+    double2 *recs = reinterpret_cast<double2 *>(ws.q12 + ((size_t)b * N + i0) * (C + 2));
+    constexpr int pairs = D + 2;
+    for (int c = tid; c < nvalid * pairs; c += TPB) {
+      const int sm = c / pairs, pr = c - sm * pairs;
+      double2 v = make_double2(0.0, 0.0);
+      if (pr < D) v = make_double2(s_Q1[pr * TPB + sm], s_Q2[pr * TPB + sm]);
+      else if (pr == D) v = make_double2(s_X[sm], s_X[TPB + sm]);
+      recs[c] = v;
+    }
+  }
+  if (!live) return;
   LdsRowsJoint r;
   r.Q1 = Q1; r.Q2 = Q2; r.lim_lo = s_lo; r.lim_hi = s_hi; r.stride = TPB; r.D = D;
   r.E = 2; r.X = X;
