@@ -377,6 +377,11 @@ void tpamd_debug_keep_boundary(tpamd_engine *engine, int on);
  * [B][64] int64: slots 0..31 of the backward wave, 32..63 of the forward wave (meaning of a
  * slot: csrc/tpamd_sweep_joint.h, JointSweep::diag). The product build leaves them zero. */
 int tpamd_debug_copy_diag(tpamd_engine *engine, int num_paths, long long *out);
+/* Registers per lane of the two hot kernels of the 7-joint path as the loaded code object
+ * reports them (hipFuncGetAttributes): which = 0 the sampling/LP kernel, 1 the sweep kernel.
+ * The pipelined modes rely on 2 x sweep + 1 x sampling/LP <= 512 (one SIMD's register file);
+ * tests/test_gpu_configs.py checks it. Negative: error code. */
+int tpamd_debug_kernel_vgprs(tpamd_engine *engine, int which);
 
 /* Per-kernel launch durations for bench.py: HIP events recorded on the launch stream
  * around each kernel (enable = 1) or around the sweep kernel only (enable = 2: two events

@@ -374,3 +374,16 @@ def test_pose_spline_sampling_matches_the_oracle(env):
         assert np.max(np.abs(np.linalg.norm(poses[b, :, 3:], axis=1) - 1.0)) <= 1e-12
         past_end += int((poses[b, :, :3] == tr[b, -1]).all(axis=1).sum())
     assert past_end >= B * 30
+
+
+def test_sweep_and_sampling_kernels_fit_one_simd_together(env):
+    """The pipelined modes run the sampling/LP kernel of the next solve beside the resident sweep
+    workgroups: one of its waves (and its 16 KB of LDS) must fit next to TWO sweep waves on a SIMD's
+    512 registers. A sweep build above 208 VGPRs silently loses that (measured: 227 VGPRs, pipelined
+    step 0.511 -> 0.534 ms)."""
+    E = env["E"]
+    k1, k2 = E.debug_kernel_vgprs(0), E.debug_kernel_vgprs(1)
+    assert 0 < k1 <= 128 and 0 < k2 <= 256, (k1, k2)
+    gran = 8                                    # VGPR allocation granule of gfx950 (wave64)
+    up = lambda n: (n + gran - 1) // gran * gran
+    assert 2 * up(k2) + up(k1) <= 512, "sweep %d + sampling/LP %d VGPRs do not fit one SIMD" % (k2, k1)

@@ -1403,6 +1403,16 @@ void tpamd_debug_keep_boundary(tpamd_engine *e, int on) {
   if (e) e->keep_boundary = on != 0;
 }
 
+int tpamd_debug_kernel_vgprs(tpamd_engine *e, int which) {
+  if (!e || which < 0 || which > 1) return TPAMD_E_INVALID_ARGUMENT;
+  TPAMD_ON_DEVICE(e);
+  hipFuncAttributes attr;
+  const void *fn = which == 0 ? reinterpret_cast<const void *>(&k_sample_lp_joint<1, 7>)
+                              : reinterpret_cast<const void *>(&k_sweep_joint<7, 0>);
+  HIPCHK(hipFuncGetAttributes(&attr, fn));
+  return attr.numRegs;
+}
+
 int tpamd_debug_copy_diag(tpamd_engine *e, int B, long long *out) {
   if (!e || !out || B != e->last_B) return TPAMD_E_INVALID_ARGUMENT;
   TPAMD_ON_DEVICE(e);

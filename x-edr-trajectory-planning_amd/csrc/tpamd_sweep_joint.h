@@ -1822,34 +1822,73 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   typename JS::Prefetch pf;
   pf.tag = -1;
   TPAMD_T0(t_all);
-  // First pair: the forward extremal from 0 may run into the backward one from N-1, so the
-  // two are sequential (time_optimal_path_timing.cc:325-326).
+  // First pair (time_optimal_path_timing.cc:325-326): the backward extremal from N-1, then the
+  // forward one from 0, which may run into it. They are run SIDE BY SIDE first: if they end more
+  // than 70 samples apart neither has seen anything of the other -- an extremal reads sd2 at
+  // most 64 samples ahead of itself (boundary following) and the two regions only grow towards
+  // each other -- so both are exactly what the sequential order produces. Otherwise (short
+  // paths, paths without a limit-curve contact) sd2 and sdd are reset and the pair is redone in
+  // order (`first_pair_in_order`, a copy of its own of the two extremals: a loop around one copy
+  // costs 30 VGPRs, and above 208 the sampling/LP kernel no longer fits beside two sweep waves).
   // qd/qdd bookkeeping of wave 0: samples below emitted_hi and from upper_lo up have been
   // written (see emit_range)
   int emitted_hi = 0, upper_lo = N;
-  if (w == 0) {
-    const int r = S.template add_extremal<false>(iback_hi, pf);
-    if (lane == 0) xchg[0] = r;
-  }
-  __threadfence_block();
-  __syncthreads();
-  if (w == 1) {
-    const int r = S.template add_extremal<true>(iforw_lo, pf);
-    if (lane == 0) xchg[1] = r;
-  } else {
-    // meanwhile: the region the first backward extremal has just set, short of its lower end
-    // (which the NaN mark below and the connecting forward extremal may still change; what
-    // the latter rewrites is redone in the tail)
+#ifndef TPAMD_FIRST_PAIR_CONCURRENT
+#define TPAMD_FIRST_PAIR_CONCURRENT 1
+#endif
 #ifndef TPAMD_EMIT_IN_LOOP
 #define TPAMD_EMIT_IN_LOOP 1
 #endif
-    if (TPAMD_EMIT_IN_LOOP) {
-      upper_lo = min(S.end_idx + 3, N);
-      S.emit_range(upper_lo, N - 1, 0, 1);
+  bool first_pair_in_order = !TPAMD_FIRST_PAIR_CONCURRENT;
+  if (TPAMD_FIRST_PAIR_CONCURRENT) {
+    if (w == 0) {
+      const int r = S.template add_extremal<false>(iback_hi, pf);
+      if (lane == 0) { xchg[0] = r; xchg[7] = S.end_idx; }
+    } else {
+      const int r = S.template add_extremal<true>(iforw_lo, pf);
+      if (lane == 0) { xchg[1] = r; xchg[8] = S.end_idx; }
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int end_b = uniform_i32(xchg[7]), end_f = uniform_i32(xchg[8]);
+    if (!(end_f + 70 < end_b)) {                     // (uniform over the workgroup)
+      // the two met or came close: back to the state before the attempt
+      first_pair_in_order = true;
+      for (int i = tid; i < N; i += 128) {
+        sd2[i] = qnan();
+        S.sdd_g[i] = qnan();
+      }
+      __syncthreads();
+      if (tid == 0) {
+        sd2[0] = sd_start * sd_start;
+        sd2[N - 1] = 0;
+      }
+      __threadfence_block();
+      __syncthreads();
     }
   }
-  __threadfence_block();
-  __syncthreads();
+  if (first_pair_in_order) {
+    if (w == 0) {
+      const int r = S.template add_extremal<false>(iback_hi, pf);
+      if (lane == 0) xchg[0] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (w == 1) {
+      const int r = S.template add_extremal<true>(iforw_lo, pf);
+      if (lane == 0) xchg[1] = r;
+    } else {
+      // meanwhile: the region the first backward extremal has just set, short of its lower end
+      // (which the NaN mark below and the connecting forward extremal may still change; what
+      // the latter rewrites is redone in the tail)
+      if (TPAMD_EMIT_IN_LOOP) {
+        upper_lo = min(S.end_idx + 3, N);
+        S.emit_range(upper_lo, N - 1, 0, 1);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   iback_lo = uniform_i32(xchg[0]);
   iforw_hi = uniform_i32(xchg[1]);
   TPAMD_ACC(9, t_all);   // first pair (sequential)

@@ -130,7 +130,7 @@ ABI_SYMBOLS = [
     "tpamd_plan_joint_windows_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
     "tpamd_resample_uniform_host", "tpamd_resample_skip_device", "tpamd_resample_skip_host",
-    "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_profile_reset", "tpamd_profile_enable",
+    "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_debug_kernel_vgprs", "tpamd_profile_reset", "tpamd_profile_enable",
     "tpamd_profile_mean_ms", "tpamd_profile_kernel_name", "tpamd_profile_num_kernels",
 ]
 
@@ -210,6 +210,8 @@ def load_library():
     L.tpamd_debug_keep_boundary.argtypes = [vp, i]
     L.tpamd_debug_copy_diag.restype = i
     L.tpamd_debug_copy_diag.argtypes = [vp, i, vp]
+    L.tpamd_debug_kernel_vgprs.restype = i
+    L.tpamd_debug_kernel_vgprs.argtypes = [vp, i]
     L.tpamd_profile_reset.argtypes = [vp]
     L.tpamd_profile_enable.argtypes = [vp, i]
     L.tpamd_profile_mean_ms.restype = C.c_double
@@ -425,6 +427,12 @@ class Engine:
     def debug_keep_boundary(self, on=True):
         """Have the fused joint sweep store sdd_max/sdd_min/type for debug_boundary()."""
         self._lib.tpamd_debug_keep_boundary(self._h, 1 if on else 0)
+
+    def debug_kernel_vgprs(self, which):
+        """Registers per lane of the 7-joint sampling/LP kernel (0) / sweep kernel (1)."""
+        n = self._lib.tpamd_debug_kernel_vgprs(self._h, which)
+        _check(min(n, 0), "tpamd_debug_kernel_vgprs")
+        return n
 
     def debug_diag(self, B):
         out = np.zeros((B, 64), dtype=np.int64)
