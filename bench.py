@@ -53,10 +53,13 @@ def algorithmic_bytes_per_path(D, N, P):
 
 
 def gather_bytes_per_path(mode, D, N):
-    """Bytes one path contributes to the gather payload: the packed timing profile
-    (t, sd, sdd; s = s_start + i*ds is rebuilt on the root) and, for "full", q as well."""
+    """Bytes one path contributes to the gather payload. compact: (sd, sdd) and the scalars
+    (ds, time_start) -- the root rebuilds t from sd (and s = s_start + i*ds, an arithmetic
+    sequence); profile: (t, sd, sdd); full: q as well."""
     if mode == "none":
         return 0
+    if mode == "compact":
+        return 8 * N * 2 + 16
     return 8 * N * 3 + (8 * N * D if mode == "full" else 0)
 
 
@@ -199,8 +202,11 @@ def main():
     ap.add_argument("--paths-per-gpu", type=int, default=0, help="override the workload's batch")
     ap.add_argument("--dofs", type=int, default=7)
     ap.add_argument("--samples", type=int, default=2000)
-    ap.add_argument("--gather", choices=("profile", "full"), default="profile",
-                    help="multi-GPU payload: the timing profile (t, sd, sdd), or q as well")
+    ap.add_argument("--gather", choices=("compact", "profile", "full"), default="compact",
+                    help="multi-GPU payload: compact = (sd, sdd) + two scalars per path, the root "
+                         "rebuilds t from sd with the solver's own operations inside the timed region "
+                         "(32 KB per path through the root's xGMI links instead of 48); profile = "
+                         "(t, sd, sdd); full = q as well")
     ap.add_argument("--pipeline", type=int, choices=(0, 1, 2), default=1,
                     help="engine pipelining across steps (tpamd_engine_set_pipelining): 0 one kernel "
                          "at a time; 1 (default) the sampling/LP kernel of step k+1 runs under the sweep of "
@@ -274,17 +280,48 @@ def main():
     # time_optimal_path_timing.cc:540-547, which the root rebuilds from per-path scalars.)
     # Two buffers, so that the gather of batch k (rank 0's inbound xGMI links) overlaps the solve
     # of batch k+1.
-    rows = 3 + (D if args.gather == "full" else 0)
-    G = shd.PipelinedGather((rows, B, N), torch.float64, dev, depth=2)
+    compact = args.gather == "compact"
     shared = eng.alloc_joint_outputs(B, N, D, dev, with_q=(args.gather != "full"))
     outs = []
-    for slot in range(2):
-        o = dict(shared)
-        p = G.send[slot]
-        o["time"], o["sd"], o["sdd"] = p[0], p[1], p[2]
-        if args.gather == "full":
-            o["q"] = p[3:].view(B, N, D)          # the engine writes q straight into the payload
-        outs.append(o)
+    if compact:
+        # flat payload per rank: sd [B][N] | sdd [B][N] | ds [B] | time_start [B]
+        flat = 2 * B * N + 2 * B
+        root_time = None
+
+        def rebuild(slot):
+            # on the root, right after the gather of this slot has landed: t of every shard's
+            # paths from its sd, ds and time_start (own shard included: one launch)
+            r0 = G.recv[slot]
+            E.rebuild_time(r0[0, :B * N], r0[0, 2 * B * N:2 * B * N + B], r0[0, 2 * B * N + B:],
+                           root_time[slot], world, B, N, flat)
+
+        G = shd.PipelinedGather((flat,), torch.float64, dev, depth=2,
+                                on_complete=rebuild if distributed else None)
+        if distributed and rank == 0:
+            root_time = [torch.empty(world * B, N, dtype=torch.float64, device=dev) for _ in range(2)]
+        # ds exactly as the set-up kernel forms it (tpamd_kernels.h k_setup_joint):
+        # s1 = s0 + delta (N - 1); ds = (s1 - s0) / (N - 1)   (IEEE fp64 on either side)
+        ps = torch.as_tensor(batch["path_start"], dtype=torch.float64, device=dev)
+        dl = torch.as_tensor(batch["delta"], dtype=torch.float64, device=dev)
+        ds_t = ((ps + dl * float(N - 1)) - ps) / float(N - 1)
+        t0_t = torch.as_tensor(batch["time_start"], dtype=torch.float64, device=dev)
+        for slot in range(2):
+            o = dict(shared)
+            p = G.send[slot]
+            o["sd"], o["sdd"] = p[:B * N].view(B, N), p[B * N:2 * B * N].view(B, N)
+            p[2 * B * N:2 * B * N + B].copy_(ds_t)
+            p[2 * B * N + B:].copy_(t0_t)
+            outs.append(o)
+    else:
+        rows = 3 + (D if args.gather == "full" else 0)
+        G = shd.PipelinedGather((rows, B, N), torch.float64, dev, depth=2)
+        for slot in range(2):
+            o = dict(shared)
+            p = G.send[slot]
+            o["time"], o["sd"], o["sdd"] = p[0], p[1], p[2]
+            if args.gather == "full":
+                o["q"] = p[3:].view(B, N, D)          # the engine writes q straight into the payload
+            outs.append(o)
     counter = [0]
 
     def step():
@@ -414,12 +451,19 @@ def main():
                        "gather": {"mode": args.gather if distributed else "none (single GPU)",
                                   "bytes_per_path": gb,
                                   "bytes_into_rank0_per_step": gb * B * (world - 1),
-                                  "what": ("ONE RCCL gather per step of the packed payload "
-                                           "(t, sd, sdd%s; s = s_start + i*ds is rebuilt on the "
-                                           "root; qd, qdd%s stay on the producing GPU) to rank 0, "
-                                           "overlapped with the next step's solve "
-                                           "(double-buffered), all inside the timed region"
-                                           % ((", q", "") if args.gather == "full" else ("", ", q")))
+                                  "what": (("ONE RCCL gather per step of the packed payload "
+                                            "(sd, sdd and the scalars ds, time_start per path; the root "
+                                            "rebuilds t from sd with the solver's operations -- "
+                                            "tpamd_rebuild_time_device, inside the timed region -- and s = "
+                                            "s_start + i*ds is an arithmetic sequence; q, qd, qdd stay on the "
+                                            "producing GPU) to rank 0, overlapped with the next step's solve "
+                                            "(double-buffered), all inside the timed region") if compact else
+                                           ("ONE RCCL gather per step of the packed payload "
+                                            "(t, sd, sdd%s; s = s_start + i*ds is rebuilt on the "
+                                            "root; qd, qdd%s stay on the producing GPU) to rank 0, "
+                                            "overlapped with the next step's solve "
+                                            "(double-buffered), all inside the timed region"
+                                            % ((", q", "") if args.gather == "full" else ("", ", q"))))
                                   if distributed else None}},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -324,6 +324,25 @@ int tpamd_query_device(tpamd_engine *engine, int num_paths, int num_samples,
                        int32_t *ok, void *hip_stream);
 
 /* ------------------------------------------------------------------------
+ * Time samples rebuilt from the velocities of solved paths: time[i] = time[i-1] +
+ * 2 ds / (sd[i-1] + sd[i]) (0 across a stationary pair), summed left to right as
+ * TimeOptimalPathProfile::OptimizePathParameter does (time_optimal_path_timing.cc:447-455) --
+ * bit-identical to the `time` output of the solve that produced sd. For the root of a multi-GPU
+ * job: shards send (sd, sdd) and the two scalars (ds, time_start) per path, the root rebuilds
+ * time. num_shards blocks of paths_per_shard paths each; block r keeps its arrays at
+ * base + r * shard_stride (in doubles): sd [paths_per_shard][num_samples] at sd, ds and
+ * time_start [paths_per_shard] at ds / time_start (pointers into shard 0). time_out is
+ * [num_shards * paths_per_shard][num_samples], densely packed. num_samples_per_path (per global
+ * path index) may be NULL. ds of a path = (s_end - s_start) / (n - 1) with
+ * s_end = path_start + delta (n - 1) (path_timing_trajectory.cc:340-341). Device pointers.
+ * ------------------------------------------------------------------------ */
+int tpamd_rebuild_time_device(tpamd_engine *engine, int num_shards, int paths_per_shard,
+                              int num_samples, size_t shard_stride, const double *sd,
+                              const double *ds, const double *time_start,
+                              const int32_t *num_samples_per_path, double *time_out,
+                              void *hip_stream);
+
+/* ------------------------------------------------------------------------
  * Uniform-in-time resample: PathTimingTrajectory::ResampleEquidistantlyInTime
  * (path_timing_trajectory.cc:755-783) with InterpolateAtTime (:709-753) for a
  * batch of solved paths. Output row b holds count[b] = ceil((t_end-start)/dt)+1

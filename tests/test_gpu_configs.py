@@ -387,3 +387,45 @@ def test_sweep_and_sampling_kernels_fit_one_simd_together(env):
     gran = 8                                    # VGPR allocation granule of gfx950 (wave64)
     up = lambda n: (n + gran - 1) // gran * gran
     assert 2 * up(k2) + up(k1) <= 512, "sweep %d + sampling/LP %d VGPRs do not fit one SIMD" % (k2, k1)
+
+
+@pytest.mark.parametrize("shards,B,N,ragged", [(1, 64, 2000, False), (3, 40, 777, False), (2, 33, 500, True)])
+def test_time_rebuilt_from_sd_equals_the_solved_time(env, shards, B, N, ragged):
+    """tpamd_rebuild_time_device (the root of a multi-GPU job rebuilds t from the gathered sd):
+    bit-identical to the solve's own time output, in the sharded payload layout bench.py uses
+    (sd | sdd | ds | time_start per shard, shard_stride doubles apart)."""
+    torch, eng, syn, E, dev = env["torch"], env["eng"], env["syn"], env["E"], env["dev"]
+    D = 7
+    flat = 2 * B * N + 2 * B
+    payload = torch.zeros(shards, flat, dtype=torch.float64, device=dev)
+    want = torch.empty(shards * B, N, dtype=torch.float64, device=dev)
+    counts = torch.full((shards * B,), N, dtype=torch.int32, device=dev)
+    for r in range(shards):
+        b = syn.make_joint_batch(B, D, N, first_path_index=1000 * r)
+        b["time_start"] = np.linspace(0.0, 3.0, B) * (r + 1)
+        if ragged:
+            b["num_samples_per_path"] = (N - (np.arange(B) * 7) % 200).astype(np.int32)
+            b["delta"] = np.ascontiguousarray(b["knots"][:, -1] / (b["num_samples_per_path"] - 1))
+        inp = eng.upload_joint_batch(b, dev)
+        if ragged:
+            inp["num_samples_per_path"] = torch.as_tensor(b["num_samples_per_path"], device=dev)
+        out = eng.alloc_joint_outputs(B, N, D, dev)
+        out["time"].fill_(-1.0)
+        E.time_joint_paths(inp, out, N)
+        torch.cuda.synchronize()
+        assert int((out["status"] == 0).sum()) == B
+        payload[r, :B * N] = out["sd"].reshape(-1)
+        nb = b["num_samples_per_path"].astype(np.float64) - 1 if ragged else np.full(B, N - 1.0)
+        ps = torch.as_tensor(b["path_start"], dtype=torch.float64, device=dev)
+        dl = torch.as_tensor(b["delta"], dtype=torch.float64, device=dev)
+        nbt = torch.as_tensor(nb, dtype=torch.float64, device=dev)
+        payload[r, 2 * B * N:2 * B * N + B] = ((ps + dl * nbt) - ps) / nbt
+        payload[r, 2 * B * N + B:] = torch.as_tensor(b["time_start"], dtype=torch.float64, device=dev)
+        want[r * B:(r + 1) * B] = out["time"]
+        if ragged:
+            counts[r * B:(r + 1) * B] = torch.as_tensor(b["num_samples_per_path"], device=dev)
+    got = torch.full((shards * B, N), -1.0, dtype=torch.float64, device=dev)
+    E.rebuild_time(payload[0, :B * N], payload[0, 2 * B * N:2 * B * N + B], payload[0, 2 * B * N + B:],
+                   got, shards, B, N, flat, num_samples_per_path=counts if ragged else None)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int64), want.view(torch.int64))

@@ -74,6 +74,47 @@ def _pipeline_worker(rank, world, port, B, N, steps, q):
         dist.destroy_process_group()
 
 
+def _hook_worker(rank, world, port, B, N, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = importlib.import_module(PKG_NAME + ".sharding")
+    try:
+        derived = []                            # what the root derives from each landed payload
+
+        def hook(slot):
+            derived.append(float(g.recv[slot].sum()))
+
+        g = sh.PipelinedGather((B * N + B,), torch.float64, "cpu", depth=2, on_complete=hook)
+        for k in range(steps):
+            buf = g.buffer(k)
+            buf.copy_(torch.full((B * N + B,), float(10 * k + rank)))
+            g.launch(k)
+        g.drain()
+        if rank == 0:
+            q.put(derived)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_gather_calls_the_roots_hook_once_per_batch_in_order():
+    world, B, N, steps = 2, 3, 5, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hook_worker, args=(r, world, port, B, N, steps, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    derived = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = B * N + B
+    assert derived == [float(n * (10 * k + 0) + n * (10 * k + 1)) for k in range(steps)]
+
+
 def test_pipelined_gather_keeps_batches_apart():
     world, B, N, steps = 2, 3, 5, 6
     ctx = mp.get_context("spawn")

@@ -1256,6 +1256,22 @@ int tpamd_find_max_sd2_host(tpamd_engine *e, int num, int C, const double *a, co
   return 0;
 }
 
+int tpamd_rebuild_time_device(tpamd_engine *e, int num_shards, int paths_per_shard, int N,
+                              size_t shard_stride, const double *sd, const double *ds,
+                              const double *time_start, const int32_t *ns, double *time_out,
+                              void *hip_stream) {
+  if (!e || !sd || !ds || !time_start || !time_out) return TPAMD_E_INVALID_ARGUMENT;
+  if (num_shards < 0 || paths_per_shard < 0 || N < 2) return TPAMD_E_INVALID_ARGUMENT;
+  const long long total = (long long)num_shards * paths_per_shard;
+  if (total == 0) return 0;
+  if (total > 0x7fffffffLL) return TPAMD_E_UNSUPPORTED;
+  TPAMD_ON_DEVICE(e);
+  hipLaunchKernelGGL(k_rebuild_time, dim3((unsigned)total), dim3(64), 0, (hipStream_t)hip_stream, N,
+                     paths_per_shard, shard_stride, sd, ds, time_start, ns, time_out);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int tpamd_query_device(tpamd_engine *e, int B, int N, int K, const double *time, const double *s,
                        const double *sd, const double *sd2, const int32_t *status,
                        const double *t_query, double *os, double *osd, double *osdd, int32_t *ok,

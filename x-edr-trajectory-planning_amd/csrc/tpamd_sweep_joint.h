@@ -2242,4 +2242,41 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// The time samples of solved paths rebuilt from their velocities: time_[i] = time_[i-1] +
+// 2 ds / (sd_[i-1] + sd_[i]), 0 across a stationary pair, summed left to right
+// (time_optimal_path_timing.cc:447-455) -- the operations of the sweep kernel's tail, hence the
+// same bits. One wave per path. Used on the root of a multi-GPU job: a shard then sends (sd, sdd)
+// and two scalars per path instead of (t, sd, sdd), a third less through the root's xGMI links.
+// Paths are addressed as shard r = p / paths_per_shard, b = p % paths_per_shard:
+//   sd   at sd_base   + r * shard_stride + b * N      (doubles)
+//   ds   at ds_base   + r * shard_stride + b,   t_start likewise
+//   out  at t_out     + (r * paths_per_shard + b) * N
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_rebuild_time(int N, int paths_per_shard, size_t shard_stride, const double *sd_base,
+               const double *ds_base, const double *t_start_base, const int32_t *ns, double *t_out) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int r = p / paths_per_shard, b = p - r * paths_per_shard;
+  const double *sd = sd_base + (size_t)r * shard_stride + (size_t)b * N;
+  const double ds = ds_base[(size_t)r * shard_stride + b];
+  double t = t_start_base[(size_t)r * shard_stride + b];
+  double *out = t_out + (size_t)p * N;
+  const int Nb = ns ? min(ns[p], N) : N;
+  OrderedSumMasks osm;
+  osm.init(lane);
+  for (int k0 = 0; k0 < Nb; k0 += 64) {
+    const int i = k0 + lane;
+    const bool in = i < Nb;
+    const double sdv = in ? sd[i] : 0.0;
+    const double sdp = (in && i >= 1) ? sd[i - 1] : 0.0;
+    double dt = 0.0;
+    if (in && i >= 1 && ((sdp > 0) || (sdv > 0))) dt = 2.0 * ds / (sdp + sdv);
+    const bool finite = __ballot(!(dt <= DBL_MAX)) == 0ull;
+    const double y = finite ? ordered_sum64_finite(t, dt, osm) : ordered_sum64(t, dt);
+    if (in) out[i] = y;
+    t = readlane_f64(y, 63);
+  }
+}
+
 }  // namespace tpamd

@@ -130,7 +130,8 @@ ABI_SYMBOLS = [
     "tpamd_plan_joint_windows_host",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
     "tpamd_resample_uniform_host", "tpamd_resample_skip_device", "tpamd_resample_skip_host",
-    "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_debug_kernel_vgprs", "tpamd_profile_reset", "tpamd_profile_enable",
+    "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_debug_kernel_vgprs",
+    "tpamd_rebuild_time_device", "tpamd_profile_reset", "tpamd_profile_enable",
     "tpamd_profile_mean_ms", "tpamd_profile_kernel_name", "tpamd_profile_num_kernels",
 ]
 
@@ -212,6 +213,8 @@ def load_library():
     L.tpamd_debug_copy_diag.argtypes = [vp, i, vp]
     L.tpamd_debug_kernel_vgprs.restype = i
     L.tpamd_debug_kernel_vgprs.argtypes = [vp, i]
+    L.tpamd_rebuild_time_device.restype = i
+    L.tpamd_rebuild_time_device.argtypes = [vp, i, i, i, C.c_size_t, vp, vp, vp, vp, vp, vp]
     L.tpamd_profile_reset.argtypes = [vp]
     L.tpamd_profile_enable.argtypes = [vp, i]
     L.tpamd_profile_mean_ms.restype = C.c_double
@@ -427,6 +430,16 @@ class Engine:
     def debug_keep_boundary(self, on=True):
         """Have the fused joint sweep store sdd_max/sdd_min/type for debug_boundary()."""
         self._lib.tpamd_debug_keep_boundary(self._h, 1 if on else 0)
+
+    def rebuild_time(self, sd, ds, time_start, out, num_shards, paths_per_shard, num_samples,
+                     shard_stride, num_samples_per_path=None, stream=None):
+        """time [num_shards * paths_per_shard][N] from sd (tpamd_rebuild_time_device). sd, ds and
+        time_start are tensors (views) that start at shard 0's data; shard r lies shard_stride
+        doubles further."""
+        _check(self._lib.tpamd_rebuild_time_device(
+            self._h, num_shards, paths_per_shard, num_samples, shard_stride, _ptr(sd), _ptr(ds),
+            _ptr(time_start), _ptr(num_samples_per_path), _ptr(out), _stream_ptr(stream)),
+            "tpamd_rebuild_time_device")
 
     def debug_kernel_vgprs(self, which):
         """Registers per lane of the 7-joint sampling/LP kernel (0) / sweep kernel (1)."""

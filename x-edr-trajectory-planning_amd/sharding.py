@@ -71,8 +71,12 @@ class PipelinedGather:
     and g.drain() before results are read / timing stops. On `dst`, result(k) is the
     [world, *shape] tensor of batch k (valid after the gather completed)."""
 
-    def __init__(self, shape, dtype, device, depth=2, dst=0, group=None):
+    def __init__(self, shape, dtype, device, depth=2, dst=0, group=None, on_complete=None):
+        """on_complete(slot): called on `dst` right after the gather into recv[slot] has been
+        waited for (the current stream is then ordered behind it) -- e.g. to launch what the
+        root derives from the payload (bench.py: the time samples rebuilt from sd)."""
         self.group, self.dst, self.depth = group, dst, depth
+        self.on_complete = on_complete
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.send = [torch.empty(shape, dtype=dtype, device=device) for _ in range(depth)]
@@ -81,6 +85,7 @@ class PipelinedGather:
             self.recv = [torch.empty((self.world,) + tuple(shape), dtype=dtype, device=device)
                          for _ in range(depth)]
         self.work = [None] * depth
+        self.batch = [0] * depth            # batch number of the gather in flight per slot
 
     def buffer(self, k, host_sync=False):
         """host_sync: also block the HOST until the gather that last read this buffer is done.
@@ -90,12 +95,15 @@ class PipelinedGather:
         if self.work[slot] is not None:
             self.work[slot].wait()      # stream-level wait for NCCL, blocking wait for gloo
             self.work[slot] = None
+            if self.on_complete is not None and self.rank == self.dst:
+                self.on_complete(slot)
             if host_sync and self.send[slot].is_cuda:
                 torch.cuda.current_stream(self.send[slot].device).synchronize()
         return self.send[slot]
 
     def launch(self, k):
         slot = k % self.depth
+        self.batch[slot] = k
         if self.world == 1:
             return
         if self.rank == self.dst:
@@ -106,10 +114,12 @@ class PipelinedGather:
                                           group=self.group, async_op=True)
 
     def drain(self):
-        for slot in range(self.depth):
+        for slot in sorted(range(self.depth), key=lambda sl: self.batch[sl]):   # oldest batch first
             if self.work[slot] is not None:
                 self.work[slot].wait()
                 self.work[slot] = None
+                if self.on_complete is not None and self.rank == self.dst:
+                    self.on_complete(slot)
 
     def result(self, k):
         slot = k % self.depth
