@@ -300,11 +300,14 @@ def main():
         if distributed and rank == 0:
             root_time = [torch.empty(world * B, N, dtype=torch.float64, device=dev) for _ in range(2)]
         # ds exactly as the set-up kernel forms it (tpamd_kernels.h k_setup_joint):
-        # s1 = s0 + delta (N - 1); ds = (s1 - s0) / (N - 1)   (IEEE fp64 on either side)
-        ps = torch.as_tensor(batch["path_start"], dtype=torch.float64, device=dev)
-        dl = torch.as_tensor(batch["delta"], dtype=torch.float64, device=dev)
-        ds_t = ((ps + dl * float(N - 1)) - ps) / float(N - 1)
-        t0_t = torch.as_tensor(batch["time_start"], dtype=torch.float64, device=dev)
+        # s1 = s0 + delta (N - 1); ds = (s1 - s0) / (N - 1) -- in numpy (IEEE fp64 division; a
+        # torch division by a Python scalar multiplies by the reciprocal, which is a bit off for
+        # 40 % of the paths and shows up in the last bits of t)
+        ps_h = np.asarray(batch["path_start"], dtype=np.float64)
+        dl_h = np.asarray(batch["delta"], dtype=np.float64)
+        ds_h = ((ps_h + dl_h * np.float64(N - 1)) - ps_h) / np.float64(N - 1)
+        ds_t = torch.from_numpy(np.ascontiguousarray(ds_h)).to(dev)
+        t0_t = torch.as_tensor(np.asarray(batch["time_start"], dtype=np.float64), device=dev)
         for slot in range(2):
             o = dict(shared)
             p = G.send[slot]
@@ -387,6 +390,22 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     E.profile_enable(False)
+    # outside the timed region: the root's rebuilt time samples of its OWN shard against the time
+    # output of its own solve (same batch every step), bit for bit
+    rebuilt_ok = None
+    if compact and distributed and rank == 0 and counter[0] > 0:
+        last = (counter[0] - 1) % 2
+        rebuilt_ok = bool(torch.equal(root_time[last][:B].view(torch.int64),
+                                      shared["time"].view(torch.int64)))
+        if not rebuilt_ok:
+            a, b_ = root_time[last][:B], shared["time"]
+            bad = (a.view(torch.int64) != b_.view(torch.int64))
+            print("bench.py: rebuilt time differs in %d of %d samples (%d paths), max abs diff %.3e; "
+                  "payload ds[0..2] %s, sd equal to local: %s"
+                  % (int(bad.sum()), bad.numel(), int(bad.any(dim=1).sum()),
+                     float((a - b_).abs().max()), G.recv[last][0, 2 * B * N:2 * B * N + 3].tolist(),
+                     bool(torch.equal(G.recv[last][0, :B * N].view(B, N), outs[last]["sd"]))),
+                  file=sys.stderr)
     # every path of the LAST timed step must have been solved (status is rewritten by each step)
     ok = int((outs[(counter[0] - 1) % 2]["status"] == 0).sum()) if counter[0] else 0
     dominant_ms = E.profile_mean_ms(eng.KERNEL_SWEEP)[0] if timing else 0.0
@@ -450,6 +469,7 @@ def main():
                                         "streams; all K steps complete inside the timed region)"}[mode],
                        "gather": {"mode": args.gather if distributed else "none (single GPU)",
                                   "bytes_per_path": gb,
+                                  "rebuilt_time_equals_local_solve": rebuilt_ok,
                                   "bytes_into_rank0_per_step": gb * B * (world - 1),
                                   "what": (("ONE RCCL gather per step of the packed payload "
                                             "(sd, sdd and the scalars ds, time_start per path; the root "
@@ -472,10 +492,12 @@ def main():
         if failed:
             print("bench.py: %d of %d paths solved in the last timed step" % (solved, total_paths),
                   file=sys.stderr)
+        if rebuilt_ok is False:
+            print("bench.py: the root's rebuilt time samples differ from its own solve", file=sys.stderr)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    if failed:
+    if failed or rebuilt_ok is False:
         raise SystemExit(3)
 
 
