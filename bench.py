@@ -167,7 +167,8 @@ def roofline_block(kernels, dominant_ms, B, D, N, P, ms_per_step):
             hb, vb = e.get("hbm_frac", 0.0), e.get("valu_busy_pct", 0.0) / 100.0
             e["limiter"] = ("fp64 VALU issue" if vb >= 0.6 else
                             "HBM bandwidth" if hb >= 0.5 else
-                            "dependent-instruction latency (neither VALU nor HBM saturated)")
+                            "per-wave instruction issue (an in-order stream issues one instruction per "
+                            "~4.4 cycles; neither the VALU nor the HBM is saturated at this occupancy)")
         d = rk.get(dom[0], {})
         if "valu_insts" in d:
             valu = {"kernel": dom[0], "insts_per_launch": d["valu_insts"],
