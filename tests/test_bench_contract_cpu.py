@@ -65,4 +65,4 @@ def test_gather_payload_bytes_and_counter_file_binding(tmp_path, monkeypatch):
     (prof / "counters.json").write_text(json.dumps(good))
     r = bench.roofline_block({"k_sweep": (0.4, 20)}, 0.4, 1024, 7, 2000, 28, 0.7)
     assert r["traffic"] == 5 and r["step_traffic"] == 5 and r["valu"]["busy_pct"] == 40.0
-    assert "latency" in r["limiter"]
+    assert "instruction issue" in r["limiter"]
