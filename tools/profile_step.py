@@ -172,6 +172,11 @@ def main():
     }
     with open(os.path.join(outdir, "counters.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    # the pass databases (~8 MB each) have been summarised: gpurun copies gpurun_out/ back only
+    # while it stays under 64 MiB
+    if os.environ.get("TPAMD_KEEP_ROCPD") != "1":
+        for db in glob.glob(os.path.join(outdir, "**", "*.db"), recursive=True):
+            os.remove(db)
     print(json.dumps(summary["kernels"], indent=1))
 
 
