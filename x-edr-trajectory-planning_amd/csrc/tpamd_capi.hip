@@ -81,6 +81,7 @@ struct tpamd_engine {
   size_t slot_bytes[2] = {0, 0};
   int slot = 0;                // workspace slot e->ws_base currently refers to
   int k1_tpb = 0;              // TPAMD_K1_TPB: threads per block of the sampling/LP kernel (A/B)
+  int k1_tpb_ragged = 64;      // TPAMD_K1_TPB_RAGGED: its upper limit for ragged batches (A/B)
   // Event timing: pending (start, stop) pairs are folded into acc_ms/acc_n and their events
   // recycled through `pool` once kMaxPendingEvents are outstanding, so a long profiled run
   // holds a bounded number of HIP events.
@@ -449,6 +450,8 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
   {
     const char *fg = std::getenv("TPAMD_FORCE_GENERIC");
     e->force_generic = fg && fg[0] == '1';
+    const char *tr = std::getenv("TPAMD_K1_TPB_RAGGED");
+    if (tr && (atoi(tr) == 64 || atoi(tr) == 128 || atoi(tr) == 256)) e->k1_tpb_ragged = atoi(tr);
     const char *tb = std::getenv("TPAMD_K1_TPB");
     e->k1_tpb = tb ? std::atoi(tb) : 0;
   }
@@ -541,8 +544,12 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
   {
     Timer t(e, fs, KI_SAMPLE_LP);
     // 128 threads (16 KB of LDS at D = 7) fit next to four resident sweep workgroups of an
-    // earlier solve; 256 otherwise
-    int tpb = (C <= 28 && !piped) ? 256 : 128;
+    // earlier solve. Otherwise the block size follows the record width (measured, K1 alone:
+    // D <= 7 0.166 / 0.174 / 0.186 ms at 256 / 128 / 64 threads; D = 14, N = 4000 0.765 / 0.734 /
+    // 0.661 ms) and ragged batches take 64-thread blocks (fewer idle threads behind a path's end:
+    // the mixed-DOF share of configs[4] 2.96 -> 2.60 ms).
+    int tpb = piped ? 128 : (D <= 7 ? 256 : (D < 14 ? 128 : 64));
+    if (!piped && in->num_samples_per_path && tpb > e->k1_tpb_ragged) tpb = e->k1_tpb_ragged;
     if (e->k1_tpb == 64 || e->k1_tpb == 128 || e->k1_tpb == 256) tpb = e->k1_tpb;
     const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)D * tpb) * 8;
     if (lds > 160 * 1024) return TPAMD_E_UNSUPPORTED;
