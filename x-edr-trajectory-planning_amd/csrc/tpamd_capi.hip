@@ -270,6 +270,7 @@ int configure_kernels_for_device(int device) {
   TPAMD_BIG_LDS(k_sample_lp_joint<1, 7>);
   TPAMD_BIG_LDS(k_sample_lp_joint<1, 8>);
   TPAMD_BIG_LDS(k_sample_lp_joint<1, 14>);
+  TPAMD_BIG_LDS(k_sample_lp_joint_wide<1, 14>);
   TPAMD_BIG_LDS(k_lp_rows<1>);
   TPAMD_BIG_LDS(k_lp_rows<2>);
   TPAMD_BIG_LDS(k_sweep<JointSource>);
@@ -559,7 +560,9 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
                      in->control_points, out->q, ws)
     if (D == 7 && !e->force_generic) TPAMD_K1(7);
     else if (D == 6 && !e->force_generic) TPAMD_K1(6);
-    else if (D == 14 && !e->force_generic) TPAMD_K1(14);
+    else if (D == 14 && !e->force_generic)
+      hipLaunchKernelGGL((k_sample_lp_joint_wide<1, 14>), grid, dim3(tpb), lds, fs, N, D, P, in->knots,
+                         in->control_points, out->q, ws);
     else if (D == 3 && !e->force_generic) TPAMD_K1(3);
     else if (D == 4 && !e->force_generic) TPAMD_K1(4);
     else if (D == 5 && !e->force_generic) TPAMD_K1(5);

@@ -177,8 +177,9 @@ __device__ __forceinline__ void boundary_point(const R &r, int C, size_t o, Work
 // DT > 0: joint count fixed at compile time (q', q'' of the thread's sample also stay in
 // registers for FindSddMax/Min); DT = 0: any D.
 template <int WORDS, int DT>
-__global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
-                                  const double *cps_g, double *q_out, Workspace ws) {
+__device__ __forceinline__ void sample_lp_joint_body(int N, int D_rt, int P, const double *knots_g,
+                                                     const double *cps_g, double *q_out,
+                                                     const Workspace &ws) {
   extern __shared__ double lds[];
   const int TPB = blockDim.x;
   const int tid = threadIdx.x;
@@ -270,6 +271,21 @@ __global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
   } else {
     boundary_point<WORDS, true>(r, C, o, ws);
   }
+}
+
+template <int WORDS, int DT>
+__global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
+                                  const double *cps_g, double *q_out, Workspace ws) {
+  sample_lp_joint_body<WORDS, DT>(N, D_rt, P, knots_g, cps_g, q_out, ws);
+}
+// The same kernel with the whole register file of two waves per SIMD at its disposal: at D = 14 the
+// LDS columns allow two waves per SIMD anyway, and the default budget (128 VGPRs: a kernel without launch bounds
+// must fit 1024 threads per block) spills 58 registers. Blocks of at most 256 threads.
+template <int WORDS, int DT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_sample_lp_joint_wide(int N, int D_rt, int P, const double *knots_g, const double *cps_g,
+                       double *q_out, Workspace ws) {
+  sample_lp_joint_body<WORDS, DT>(N, D_rt, P, knots_g, cps_g, q_out, ws);
 }
 
 // Sampling only (TimeableJointSplinePath::SamplePath as a stand-alone call,
