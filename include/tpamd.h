@@ -75,9 +75,13 @@ int tpamd_engine_reserve(tpamd_engine *engine, int num_paths, int num_samples,
  *      PREVIOUS solve when a call returns; tpamd_engine_fence orders it behind all of them.
  * Contract while a mode is on: the inputs of a call (and its out->q buffer) must be ready when the
  * call is made -- the front stage is NOT ordered behind earlier work on the caller's stream -- and
- * must stay untouched until the caller's stream has passed the call (mode 2: the fence). Calls
- * captured into a HIP graph run unpipelined. 0 = off (default); changing the mode waits for the
- * engine's streams. */
+ * must stay untouched until the caller's stream has passed the call (mode 2: the fence). Only
+ * tpamd_time_joint_paths_device is pipelined: the _host entry points and every other solve
+ * (rows, Cartesian, planning windows, joint groups) run in order on the caller's stream and are
+ * ordered against the engine's streams where they share a workspace with pipelined solves. Calls
+ * captured into a HIP graph run unpipelined; fence and synchronise the engine before capturing
+ * (a captured stream cannot wait for work outside the capture). 0 = off (default); changing the
+ * mode waits for the engine's streams. */
 int tpamd_engine_set_pipelining(tpamd_engine *engine, int mode);
 /* Make hip_stream wait for every solve issued so far (needed in mode 2 before the outputs of the
  * last solve are used; harmless otherwise). */
@@ -121,7 +125,8 @@ typedef struct tpamd_joint_inputs {
   const double *time_start;     /* [B]  SetupProblem time_start */
   /* Ragged batches (BASELINE.json configs[4]): samples of each path, 3 <= n[b] <=
    * num_samples; NULL = every path has num_samples. All [B][N]-shaped arrays keep the
-   * stride num_samples; entries beyond n[b] are not written. */
+   * stride num_samples; entries beyond n[b] are not written. The sweep then takes the paths
+   * longest first (a device-side counting sort), whatever their order in the batch. */
   const int32_t *num_samples_per_path; /* [B] or NULL */
 } tpamd_joint_inputs;
 
@@ -145,6 +150,27 @@ int tpamd_time_joint_paths_device(tpamd_engine *engine, const tpamd_joint_batch 
 int tpamd_time_joint_paths_host(tpamd_engine *engine, const tpamd_joint_batch *batch,
                                 const tpamd_joint_inputs *in,
                                 const tpamd_path_outputs *out);
+
+/* Several joint-space batches solved CONCURRENTLY (BASELINE.json configs[4]: a mixed 6/7/14-joint
+ * batch with 500..4000 samples per path). The kernels are specialised on the joint count, and a
+ * launch's LDS is sized by its sample stride, so a mixed batch is bucketed by the caller into
+ * groups of one (num_dofs, num_points, stride) each -- BatchPathTiming buckets by
+ * (D, P, ceil(N / 512)) -- and every group is what tpamd_time_joint_paths_* takes. Here the groups
+ * of one call run side by side: the groups are taken heaviest first (stride x joints) and dealt
+ * to the engine's lanes (a stream and a workspace of the engine's own each; four, the number of
+ * hardware queues the runtime uses), the heaviest on the highest-priority lane; their sampling/LP
+ * kernels run one after another in that order, their sweeps overlap. The
+ * lanes fork from hip_stream's position at the call and hip_stream waits for all of them before it
+ * goes on, so for the caller the call behaves like one solve on hip_stream. Within a ragged group
+ * the sweep takes the paths longest first (as tpamd_time_joint_paths_* does). Never pipelined.
+ * Same per-path results as separate calls, bit for bit. batches/inputs/outputs: [num_groups]. */
+int tpamd_time_joint_groups_device(tpamd_engine *engine, int num_groups,
+                                   const tpamd_joint_batch *batches,
+                                   const tpamd_joint_inputs *inputs,
+                                   const tpamd_path_outputs *outputs, void *hip_stream);
+int tpamd_time_joint_groups_host(tpamd_engine *engine, int num_groups,
+                                 const tpamd_joint_batch *batches, const tpamd_joint_inputs *inputs,
+                                 const tpamd_path_outputs *outputs);
 
 /* Stand-alone batched TimeableJointSplinePath::SamplePath
  * (timeable_path_joint_spline.cc:294-318): q, q' = dq/ds, q'' = d2q/ds2 at

@@ -79,9 +79,12 @@ def cartesian_case(name, B, D, N, check=32):
                       "cpu_oracle_64_threads_paths_per_s": round(cpu, 1)}), flush=True)
 
 
-def mixed_case(name, per_group, check=8):
+def mixed_case(name, per_group, check=8, bucket=512):
+    """3 x per_group paths of 6/7/14 joints, 500..4000 samples each. Timed two ways: the DOF groups
+    one after another at their common stride (how round 2 ran it), and bucketed by
+    (D, ceil(N / bucket)) with all buckets side by side (tpamd_time_joint_groups_device)."""
     rng = np.random.default_rng(11)
-    groups = []
+    groups, buckets = [], []
     for D in (6, 7, 14):
         ns = rng.integers(500, 4001, size=per_group).astype(np.int32)
         stride = int(ns.max())
@@ -91,23 +94,35 @@ def mixed_case(name, per_group, check=8):
         inp["num_samples_per_path"] = torch.from_numpy(ns).to(DEV)
         out = eng.alloc_joint_outputs(per_group, stride, D, DEV)
         groups.append((D, ns, stride, b, inp, out))
+        edges = -(-ns // bucket) * bucket if bucket else np.full_like(ns, stride)
+        for edge in np.unique(edges):
+            pos = np.nonzero(edges == edge)[0]
+            bs = min(int(edge), stride)
+            binp = {k: v[torch.from_numpy(pos).to(DEV)].contiguous() for k, v in inp.items()}
+            bout = eng.alloc_joint_outputs(len(pos), bs, D, DEV)
+            buckets.append(dict(D=D, pos=pos, inputs=binp, outputs=bout, num_samples=bs))
 
-    def run():
+    def run_sequential():
         for D, ns, stride, b, inp, out in groups:
             E.time_joint_paths(inp, out, stride)
 
-    for _ in range(2):
-        run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    steps = 5
-    for _ in range(steps):
-        run()
-    torch.cuda.synchronize()
-    el = (time.perf_counter() - t0) / steps
-    exact, solved, samples = True, 0, 0
+    def run_groups():
+        E.time_joint_groups(buckets)
+
+    def clock(fn, steps=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    el_seq = clock(run_sequential)
+    el = clock(run_groups)
+    exact, solved, samples, same = True, 0, 0, True
     for D, ns, stride, b, inp, out in groups:
-        solved += int((out["status"] == 0).sum())
         samples += int(ns.sum())
         for i in range(check):
             one = {k: b[k][i:i + 1] for k in ("knots", "control_points", "vmax", "amax", "path_start", "delta")}
@@ -119,17 +134,37 @@ def mixed_case(name, per_group, check=8):
                 for k in ("time", "sd", "qdd"):
                     exact = exact and np.array_equal(out[k][i, :ns[i]].cpu().numpy(),
                                                      ref["t" if k == "time" else k][0])
+        # every path of the bucketed run against the sequential run of the same engine
+        for bk in buckets:
+            if bk["D"] != D:
+                continue
+            st = bk["outputs"]["status"].cpu().numpy()
+            solved += int((st == 0).sum())
+            for j, p_ in enumerate(bk["pos"]):
+                n = int(ns[p_])
+                for k in ("time", "sd", "sdd", "qd", "qdd"):
+                    same = same and torch.equal(bk["outputs"][k][j, :n], out[k][p_, :n])
     B = 3 * per_group
     print(json.dumps({"case": name, "paths": B, "dofs": [6, 7, 14], "samples": "500..4000 per path",
-                      "total_samples": samples, "ms_per_batch": round(el * 1e3, 3),
-                      "paths_per_s": round(B / el, 1), "samples_per_s": round(samples / el, 1),
+                      "total_samples": samples, "buckets": len(buckets),
+                      "ms_per_batch": round(el * 1e3, 3), "paths_per_s": round(B / el, 1),
+                      "samples_per_s": round(samples / el, 1),
+                      "dof_groups_in_turn_ms": round(el_seq * 1e3, 3),
+                      "dof_groups_in_turn_paths_per_s": round(B / el_seq, 1),
                       "solved": solved, "oracle_sample": 3 * check,
-                      "bit_exact_on_sample": bool(exact)}), flush=True)
+                      "bit_exact_on_sample": bool(exact),
+                      "buckets_equal_dof_groups_on_every_path": bool(same)}), flush=True)
 
 
 if __name__ == "__main__":
+    cases = sys.argv[1:] or ["1", "2", "3", "4"]     # which BASELINE.json configs to run
     print(json.dumps({"device": torch.cuda.get_device_name(0)}), flush=True)
-    joint_case("configs[1] 1024 x 7-DOF x 2000", 1024, 7, 2000)
-    joint_case("configs[2] per-GPU share: 8192 x 7-DOF x 2000", 8192, 7, 2000)
-    cartesian_case("configs[3] 4096 x 6-DOF Cartesian x 2000", 4096, 6, 2000)
-    mixed_case("configs[4] one-GPU share: 3 x 512 paths, 6/7/14-DOF, ragged", 512)
+    if "1" in cases:
+        joint_case("configs[1] 1024 x 7-DOF x 2000", 1024, 7, 2000)
+    if "2" in cases:
+        joint_case("configs[2] per-GPU share: 8192 x 7-DOF x 2000", 8192, 7, 2000)
+    if "3" in cases:
+        cartesian_case("configs[3] 4096 x 6-DOF Cartesian x 2000", 4096, 6, 2000)
+    if "4" in cases:
+        mixed_case("configs[4] one-GPU share: 3 x 512 paths, 6/7/14-DOF, ragged", 512,
+                   bucket=int(os.environ.get("TPAMD_BUCKET", "512")))

@@ -13,7 +13,8 @@
 #include <vector>
 
 #include "tpamd_kernels.h"
-#include "tpamd_sweep_joint.h"
+#include "tpamd_launch.h"
+#include "tpamd_sweep_joint.h"   // LDS layout, tile size, k_rebuild_time; the kernel instances live in tpamd_sweep_inst.hip
 
 using namespace tpamd;
 
@@ -80,6 +81,25 @@ struct tpamd_engine {
   void *slot_base[2] = {nullptr, nullptr};   // ws_base / ws_bytes of the slot not in use
   size_t slot_bytes[2] = {0, 0};
   int slot = 0;                // workspace slot e->ws_base currently refers to
+  // Concurrent groups (tpamd_time_joint_groups_*): each lane is a stream of the engine with a
+  // workspace of its own; the groups of one call are spread over the lanes and run side by side.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    hipEvent_t front = nullptr;   // this lane's sampling/LP kernel has finished
+    void *base = nullptr;
+    size_t bytes = 0;
+  };
+  static constexpr int kMaxLanes = 8;
+  Lane lanes[kMaxLanes];
+  hipEvent_t ev_fork = nullptr;
+  bool in_lane = false;        // a lane's workspace is swapped in: no slot bookkeeping
+  hipEvent_t front_wait = nullptr, front_record = nullptr;   // see tpamd_time_joint_groups_device
+  int phase = 0;               // joint solve: 0 all of it, 1 the front stage only, 2 the rest only
+  std::vector<hipEvent_t> back_wait;   // phase 2: events the sweep's stream waits for first
+  int max_lanes = 4;           // TPAMD_LANES: lanes used side by side (the runtime has 4 hardware queues)
+  int chain_fronts = 2;        // TPAMD_CHAIN_FRONTS: 0 none, 1 every front stage behind the previous group's, 2 behind the heaviest group's (A/B)
+  bool order_ragged = true;    // TPAMD_ORDER_RAGGED=0: A/B the longest-first order of ragged batches
   int k1_tpb = 0;              // TPAMD_K1_TPB: threads per block of the sampling/LP kernel (A/B)
   int k1_tpb_ragged = 64;      // TPAMD_K1_TPB_RAGGED: its upper limit for ragged batches (A/B)
   // Event timing: pending (start, stop) pairs are folded into acc_ms/acc_n and their events
@@ -130,6 +150,7 @@ size_t carve_workspace(char *base, int B, int N, int C, Workspace *ws) {
   w.type = (uint8_t *)take(ns);
   w.sd2 = (double *)take(ns * 8);
   w.diag = (long long *)take(nb * 64 * 8);
+  w.order = (const int32_t *)take(nb * 4);
   if (ws) *ws = w;
   return off;
 }
@@ -157,6 +178,36 @@ void select_slot(tpamd_engine *e, int slot) {
   e->ws_bytes = e->slot_bytes[slot];
   e->slot = slot;
 }
+
+bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+}
+
+// Every entry point that touches the CURRENT workspace slot from the caller's stream while the
+// engine has streams of its own (a pipelined mode is or was on) goes through this guard: the
+// caller's stream first waits for the front stage and the sweep that last used the slot (they may
+// still be running on the engine's streams), and the slot's "sweep done" event is re-recorded on
+// the caller's stream afterwards, so that the next pipelined front stage that takes the slot is
+// ordered behind this user. A stream that is being captured cannot wait for outside events: the
+// caller must have fenced the engine before capturing (include/tpamd.h).
+struct SlotGuard {
+  tpamd_engine *e;
+  hipStream_t st;
+  int slot;
+  bool on;
+  SlotGuard(tpamd_engine *e_, hipStream_t st_, bool record_after = true, bool enable = true)
+      : e(e_), st(st_), slot(e_->slot),
+        on(enable && !e_->in_lane && e_->aux != nullptr && !stream_is_capturing(st_)) {
+    if (!on) return;
+    (void)hipStreamWaitEvent(st, e->ev_front[slot], 0);
+    (void)hipStreamWaitEvent(st, e->ev_sweep[slot], 0);
+    on = record_after;
+  }
+  ~SlotGuard() {
+    if (on) (void)hipEventRecord(e->ev_sweep[slot], st);
+  }
+};
 
 int ensure_stage(tpamd_engine *e, size_t need) {
   if (need > e->stage_bytes) {
@@ -275,15 +326,9 @@ int configure_kernels_for_device(int device) {
   TPAMD_BIG_LDS(k_lp_rows<2>);
   TPAMD_BIG_LDS(k_sweep<JointSource>);
   TPAMD_BIG_LDS(k_sweep<GenericSource>);
-  TPAMD_BIG_LDS(k_sweep_joint<3>);
-  TPAMD_BIG_LDS(k_sweep_joint<4>);
-  TPAMD_BIG_LDS(k_sweep_joint<5>);
-  TPAMD_BIG_LDS(k_sweep_joint<6>);
-  TPAMD_BIG_LDS(k_sweep_joint<7>);
-  TPAMD_BIG_LDS(k_sweep_joint<8>);
-  TPAMD_BIG_LDS(k_sweep_joint<14>);
-  TPAMD_BIG_LDS(k_sweep_joint<6, 2>);
-  TPAMD_BIG_LDS(k_sweep_joint<7, 2>);
+#define TPAMD_CONFIGURE_SWEEP(D, E) HIPCHK((configure_sweep_joint<D, E>()));
+  TPAMD_SWEEP_INSTANCES(TPAMD_CONFIGURE_SWEEP)
+#undef TPAMD_CONFIGURE_SWEEP
   TPAMD_BIG_LDS(k_cartesian_lp<1, 6>);
   TPAMD_BIG_LDS(k_cartesian_lp<1, 7>);
   TPAMD_BIG_LDS(k_resample_skip, 128 * 1024);   // int[N], N <= 32768, next to 8 B static
@@ -313,13 +358,10 @@ template <>
 bool launch_sweep<JointSource>(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
                                const Workspace &ws, const tpamd_path_outputs *out,
                                bool force_generic) {
-#define TPAMD_LAUNCH_JOINT(DD)                                                                   \
-  do {                                                                                           \
-    hipLaunchKernelGGL((k_sweep_joint<DD>), dim3(B), dim3(128), sweep_joint_lds_bytes<DD>(N), st, \
-                       N, max_loops, src, ws, out->time, out->s, out->sd, out->sdd,              \
-                       out->last_extremal_index, out->max_time_increment, out->status, out->qd,  \
-                       out->qdd);                                                                \
-    return true;                                                                                 \
+#define TPAMD_LAUNCH_JOINT(DD)                                              \
+  do {                                                                      \
+    launch_sweep_joint<DD, 0>(B, st, N, max_loops, src, ws, out);           \
+    return true;                                                            \
   } while (0)
   if (!force_generic) {
     switch (src.D) {
@@ -379,10 +421,7 @@ int run_boundary_and_sweep(tpamd_engine *e, hipStream_t st, int B, int N, int ma
 template <int DD>
 void launch_sweep_cartesian(hipStream_t st, int B, int N, int max_loops, const JointSource &src,
                             const Workspace &ws, const tpamd_path_outputs *out) {
-  hipLaunchKernelGGL((k_sweep_joint<DD, 2>), dim3(B), dim3(128),
-                     (sweep_joint_lds_bytes<DD, 2>(N)), st, N, max_loops, src, ws, out->time,
-                     out->s, out->sd, out->sdd, out->last_extremal_index,
-                     out->max_time_increment, out->status, out->qd, out->qdd);
+  launch_sweep_joint<DD, 2>(B, st, N, max_loops, src, ws, out);
 }
 
 // LP boundary points of explicit rows, then the shared tail.
@@ -453,6 +492,12 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
     e->force_generic = fg && fg[0] == '1';
     const char *tr = std::getenv("TPAMD_K1_TPB_RAGGED");
     if (tr && (atoi(tr) == 64 || atoi(tr) == 128 || atoi(tr) == 256)) e->k1_tpb_ragged = atoi(tr);
+    const char *ml = std::getenv("TPAMD_LANES");
+    if (ml && std::atoi(ml) >= 1 && std::atoi(ml) <= tpamd_engine::kMaxLanes) e->max_lanes = std::atoi(ml);
+    const char *cf = std::getenv("TPAMD_CHAIN_FRONTS");
+    if (cf && cf[0] >= '0' && cf[0] <= '3') e->chain_fronts = cf[0] - '0';
+    const char *orr = std::getenv("TPAMD_ORDER_RAGGED");
+    e->order_ragged = !(orr && orr[0] == '0');
     const char *tb = std::getenv("TPAMD_K1_TPB");
     e->k1_tpb = tb ? std::atoi(tb) : 0;
   }
@@ -474,6 +519,13 @@ void tpamd_engine_destroy(tpamd_engine *e) {
     if (e->sweep_stream[k]) (void)hipStreamDestroy(e->sweep_stream[k]);
   }
   if (e->aux) (void)hipStreamDestroy(e->aux);
+  for (auto &ln : e->lanes) {
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+    if (ln.done) (void)hipEventDestroy(ln.done);
+    if (ln.front) (void)hipEventDestroy(ln.front);
+    if (ln.base) (void)hipFree(ln.base);
+  }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->stage_base) (void)hipFree(e->stage_base);
   if (e->rows_base) (void)hipFree(e->rows_base);
   delete e;
@@ -498,7 +550,8 @@ namespace {
 // The joint-space solve; `plan` (window chaining, tpamd_plan_joint_windows_host) adds two small
 // kernels: skip marks after the set-up kernel, the start-velocity projection after K1.
 int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_inputs *in,
-                const tpamd_path_outputs *out, void *hip_stream, const PlanParams *plan) {
+                const tpamd_path_outputs *out, void *hip_stream, const PlanParams *plan,
+                bool allow_pipelining = true) {
   if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
   const int B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples, P = bt->num_points;
   if (B <= 0) return B == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
@@ -514,18 +567,28 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
   // stage goes to the engine's stream, ordered only behind the sweep that last used this
   // workspace -- not behind the caller's stream (see tpamd_engine_set_pipelining). A stream that
   // is being captured into a graph cannot fork into the engine's stream: plain order then.
-  bool piped = e->pipelining != 0 && plan == nullptr;
-  if (piped) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) piped = false;
-  }
+  bool piped = e->pipelining != 0 && plan == nullptr && allow_pipelining;
+  if (piped && stream_is_capturing(st)) piped = false;
+  // the block size of the sampling/LP kernel and its LDS: checked before anything is launched or
+  // the workspace slot changes
+  int tpb = piped ? 128 : (D <= 7 ? 256 : (D < 14 ? 128 : 64));
+  if (!piped && in->num_samples_per_path && tpb > e->k1_tpb_ragged) tpb = e->k1_tpb_ragged;
+  if (e->k1_tpb == 64 || e->k1_tpb == 128 || e->k1_tpb == 256) tpb = e->k1_tpb;
+  const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)D * tpb) * 8;
+  if (lds > 160 * 1024) return TPAMD_E_UNSUPPORTED;
   if (piped) select_slot(e, 1 - e->slot);
   const int slot = e->slot;
+  // an unpipelined solve on an engine with streams of its own: ordered against them
+  SlotGuard slot_guard(e, st, /*record_after=*/true, /*enable=*/!piped);
   int rc = ensure_workspace(e, B, N, C);
   if (rc) return rc;
   e->last_B = B; e->last_N = N; e->last_time = out->time;
   e->ws.ns = in->num_samples_per_path;
   e->ws.amax = in->max_acceleration;
+  // ragged batches: sweep workgroups take the paths longest first (k_order_paths, below)
+  int32_t *order = const_cast<int32_t *>(e->ws.order);
+  const bool ordered = in->num_samples_per_path != nullptr && B > 1 && e->order_ragged && plan == nullptr;
+  if (!ordered) e->ws.order = nullptr;
   const Workspace &ws = e->ws;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;  // 0: per path, max(100, 10 n)
   hipStream_t fs = st;                  // stream of the front stage
@@ -533,7 +596,8 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
     fs = e->aux;
     HIPCHK(hipStreamWaitEvent(fs, e->ev_sweep[slot], 0));
   }
-  {
+  const bool do_front = e->phase != 2, do_back = e->phase != 1;
+  if (do_front) {
     Timer t(e, fs, KI_SETUP);
     hipLaunchKernelGGL(k_setup_joint, dim3((B + 127) / 128), dim3(128), 0, fs, B, N, D,
                        bt->constraint_safety, in->max_velocity, in->max_acceleration,
@@ -541,19 +605,17 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
                        ws);
     if (plan)
       hipLaunchKernelGGL(k_plan_mark_skipped, dim3((B + 127) / 128), dim3(128), 0, fs, *plan, ws);
+    if (ordered)
+      hipLaunchKernelGGL(k_order_paths, dim3(1), dim3(1024), 0, fs, B, N, in->num_samples_per_path, order);
   }
-  {
+  if (do_front && e->front_wait) HIPCHK(hipStreamWaitEvent(fs, e->front_wait, 0));
+  if (do_front) {
     Timer t(e, fs, KI_SAMPLE_LP);
-    // 128 threads (16 KB of LDS at D = 7) fit next to four resident sweep workgroups of an
-    // earlier solve. Otherwise the block size follows the record width (measured, K1 alone:
+    // (tpb, above) 128 threads (16 KB of LDS at D = 7) fit next to four resident sweep workgroups
+    // of an earlier solve. Otherwise the block size follows the record width (measured, K1 alone:
     // D <= 7 0.166 / 0.174 / 0.186 ms at 256 / 128 / 64 threads; D = 14, N = 4000 0.765 / 0.734 /
     // 0.661 ms) and ragged batches take 64-thread blocks (fewer idle threads behind a path's end:
     // the mixed-DOF share of configs[4] 2.96 -> 2.60 ms).
-    int tpb = piped ? 128 : (D <= 7 ? 256 : (D < 14 ? 128 : 64));
-    if (!piped && in->num_samples_per_path && tpb > e->k1_tpb_ragged) tpb = e->k1_tpb_ragged;
-    if (e->k1_tpb == 64 || e->k1_tpb == 128 || e->k1_tpb == 256) tpb = e->k1_tpb;
-    const size_t lds = ((size_t)(P + 3) + (size_t)P * D + 2 * C + 2 * (size_t)D * tpb) * 8;
-    if (lds > 160 * 1024) return TPAMD_E_UNSUPPORTED;
     const dim3 grid((N + tpb - 1) / tpb, B);
 #define TPAMD_K1(DD)                                                                         \
   hipLaunchKernelGGL((k_sample_lp_joint<1, DD>), grid, dim3(tpb), lds, fs, N, D, P, in->knots, \
@@ -571,6 +633,12 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
 #undef TPAMD_K1
     if (plan) hipLaunchKernelGGL(k_plan_project, dim3((B + 127) / 128), dim3(128), 0, fs, *plan, ws);
   }
+  if (do_front && e->front_record) HIPCHK(hipEventRecord(e->front_record, fs));
+  if (!do_back) {
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  for (hipEvent_t ev : e->back_wait) HIPCHK(hipStreamWaitEvent(st, ev, 0));
   // Mode 2: the sweep goes to one of two engine streams as well, so that it can start while the
   // previous solve's slowest paths are still running; it is ordered behind this call's position
   // in the caller's stream (the output buffers are free) and behind its own front stage. The
@@ -590,7 +658,10 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
   src.q12 = ws.q12; src.lim = ws.lim; src.D = D;
   bool fused = false;
   rc = run_boundary_and_sweep(e, st, B, N, max_loops, src, out, &fused);
-  if (rc) return rc;
+  if (rc) {
+    if (piped) (void)hipEventRecord(e->ev_sweep[slot], st);   // the slot's next user waits for what was launched
+    return rc;
+  }
   if (!fused && (out->qd || out->qdd)) {   // the specialised sweep kernels write qd/qdd themselves
     Timer t(e, st, KI_EPILOGUE);
     const size_t total = (size_t)B * N * D;
@@ -847,10 +918,12 @@ int tpamd_optimize_rows_device(tpamd_engine *e, const tpamd_rows_batch *bt,
     return TPAMD_E_INVALID_ARGUMENT;
   TPAMD_ON_DEVICE(e);
   hipStream_t st = (hipStream_t)hip_stream;
+  SlotGuard slot_guard(e, st);
   int rc = ensure_workspace(e, B, N, 1);
   if (rc) return rc;
   e->last_B = B; e->last_N = N; e->last_time = out->time;
   e->ws.ns = nullptr;
+  e->ws.order = nullptr;
   const Workspace &ws = e->ws;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 100;
   {
@@ -878,10 +951,12 @@ int tpamd_time_cartesian_paths_device(tpamd_engine *e, const tpamd_cartesian_bat
   const int C = 2 * D + 2;
   const int max_loops = bt->max_solver_loops > 0 ? bt->max_solver_loops : 0;
   const bool fused = (D == 6 || D == 7) && !e->force_generic;
+  SlotGuard slot_guard(e, st);
   int rc = ensure_workspace(e, B, N, C);
   if (rc) return rc;
   e->last_B = B; e->last_N = N; e->last_time = out->time;
   e->ws.ns = nullptr;
+  e->ws.order = nullptr;
   e->ws.amax = in->max_acceleration;
   {
     Timer t(e, st, KI_SETUP);
@@ -1020,65 +1095,265 @@ int tpamd_time_cartesian_paths_host(tpamd_engine *e, const tpamd_cartesian_batch
 
 // ---- host-buffer convenience paths ---------------------------------------
 
-int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
-                                const tpamd_joint_inputs *in, const tpamd_path_outputs *out) {
-  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+}  // extern "C"
+
+namespace {
+// Device copies of one joint batch's host arrays inside the staging buffer.
+struct JointStage {
+  double *knots, *cp, *vmax, *amax, *ps, *dl, *sd0, *sdd0, *t0;
+  double *t, *s, *sd, *sdd, *q, *qd, *qdd, *dtm, *sd2;
+  int32_t *lei, *st, *ns;
+};
+
+void carve_joint_stage(Stage &s, const tpamd_joint_batch *bt, const tpamd_joint_inputs *in,
+                       const tpamd_path_outputs *out, JointStage *j) {
   const size_t B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples, P = bt->num_points;
-  if (bt->num_paths <= 0) return bt->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  j->knots = s.take<double>(B * (P + 3)); j->cp = s.take<double>(B * P * D);
+  j->vmax = s.take<double>(B * D); j->amax = s.take<double>(B * D);
+  j->ps = s.take<double>(B); j->dl = s.take<double>(B); j->sd0 = s.take<double>(B);
+  j->sdd0 = s.take<double>(B); j->t0 = s.take<double>(B);
+  j->t = s.take<double>(B * N); j->s = s.take<double>(B * N);
+  j->sd = s.take<double>(B * N); j->sdd = s.take<double>(B * N);
+  j->q = out->q ? s.take<double>(B * N * D) : nullptr;
+  j->qd = out->qd ? s.take<double>(B * N * D) : nullptr;
+  j->qdd = out->qdd ? s.take<double>(B * N * D) : nullptr;
+  j->lei = s.take<int32_t>(B); j->st = s.take<int32_t>(B);
+  j->dtm = s.take<double>(B);
+  j->sd2 = out->sd2 ? s.take<double>(B * N) : nullptr;
+  j->ns = in->num_samples_per_path ? s.take<int32_t>(B) : nullptr;
+}
+
+int upload_joint_stage(const JointStage &j, const tpamd_joint_batch *bt, const tpamd_joint_inputs *in,
+                       hipStream_t st) {
+  const size_t B = bt->num_paths, D = bt->num_dofs, P = bt->num_points;
+  if (j.ns) HIPCHK(hipMemcpyAsync(j.ns, in->num_samples_per_path, B * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j.knots, in->knots, B * (P + 3) * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j.cp, in->control_points, B * P * D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j.vmax, in->max_velocity, B * D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j.amax, in->max_acceleration, B * D * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j.ps, in->path_start, B * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j.dl, in->delta, B * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(j.sd0, in->sd_start, B * 8, hipMemcpyHostToDevice, st));
+  if (in->sdd_start)
+    HIPCHK(hipMemcpyAsync(j.sdd0, in->sdd_start, B * 8, hipMemcpyHostToDevice, st));
+  else
+    HIPCHK(hipMemsetAsync(j.sdd0, 0, B * 8, st));
+  HIPCHK(hipMemcpyAsync(j.t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
+  return 0;
+}
+
+int download_joint_stage(const JointStage &j, const tpamd_joint_batch *bt, const tpamd_path_outputs *out,
+                         hipStream_t st) {
+  const size_t B = bt->num_paths, D = bt->num_dofs, N = bt->num_samples;
+  if (out->sd2) HIPCHK(hipMemcpyAsync(out->sd2, j.sd2, B * N * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out->time, j.t, B * N * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out->s, j.s, B * N * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out->sd, j.sd, B * N * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out->sdd, j.sdd, B * N * 8, hipMemcpyDeviceToHost, st));
+  if (out->q) HIPCHK(hipMemcpyAsync(out->q, j.q, B * N * D * 8, hipMemcpyDeviceToHost, st));
+  if (out->qd) HIPCHK(hipMemcpyAsync(out->qd, j.qd, B * N * D * 8, hipMemcpyDeviceToHost, st));
+  if (out->qdd) HIPCHK(hipMemcpyAsync(out->qdd, j.qdd, B * N * D * 8, hipMemcpyDeviceToHost, st));
+  if (out->last_extremal_index)
+    HIPCHK(hipMemcpyAsync(out->last_extremal_index, j.lei, B * 4, hipMemcpyDeviceToHost, st));
+  if (out->max_time_increment)
+    HIPCHK(hipMemcpyAsync(out->max_time_increment, j.dtm, B * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(out->status, j.st, B * 4, hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
+bool joint_host_args_ok(const tpamd_joint_batch *bt, const tpamd_joint_inputs *in,
+                        const tpamd_path_outputs *out) {
+  return bt->num_dofs >= 1 && bt->num_samples >= 1 && bt->num_points >= 1 && in->knots &&
+         in->control_points && in->max_velocity && in->max_acceleration && in->path_start && in->delta &&
+         in->sd_start && in->time_start && out->time && out->s && out->sd && out->sdd && out->status;
+}
+
+// Lane k of the engine: created on first use. Lane 0 gets the highest stream priority (it is
+// given the group with the longest critical path, see tpamd_time_joint_groups_device).
+int ensure_lane(tpamd_engine *e, int k) {
+  tpamd_engine::Lane &ln = e->lanes[k];
+  if (ln.stream) return 0;
+  int least = 0, greatest = 0;
+  HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  const char *pr = std::getenv("TPAMD_LANE_PRIORITY");   // A/B: "0" = all lanes at the default priority
+  const int prio = (k == 0 && !(pr && pr[0] == '0')) ? greatest : 0;
+  HIPCHK(hipStreamCreateWithPriority(&ln.stream, hipStreamNonBlocking, prio));
+  HIPCHK(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ln.front, hipEventDisableTiming));
+  if (!e->ev_fork) HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  return 0;
+}
+
+// Run `fn` with lane k's workspace in place of the engine's current one.
+template <class F>
+int with_lane_workspace(tpamd_engine *e, int k, F fn) {
+  tpamd_engine::Lane &ln = e->lanes[k];
+  std::swap(e->ws_base, ln.base);
+  std::swap(e->ws_bytes, ln.bytes);
+  const Workspace saved = e->ws;
+  e->in_lane = true;
+  const int rc = fn(ln.stream);
+  e->in_lane = false;
+  e->ws = saved;
+  std::swap(e->ws_base, ln.base);
+  std::swap(e->ws_bytes, ln.bytes);
+  return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int tpamd_time_joint_groups_device(tpamd_engine *e, int num_groups, const tpamd_joint_batch *batches,
+                                   const tpamd_joint_inputs *inputs, const tpamd_path_outputs *outputs,
+                                   void *hip_stream) {
+  if (!e || num_groups < 0 || (num_groups > 0 && (!batches || !inputs || !outputs)))
+    return TPAMD_E_INVALID_ARGUMENT;
+  if (num_groups == 0) return 0;
   TPAMD_ON_DEVICE(e);
+  hipStream_t caller = (hipStream_t)hip_stream;
+  // heaviest first: the group whose longest path has the longest sweep (about stride x joints)
+  std::vector<int> idx(num_groups);
+  for (int g = 0; g < num_groups; g++) idx[g] = g;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {
+    return (long long)batches[a].num_samples * batches[a].num_dofs >
+           (long long)batches[b].num_samples * batches[b].num_dofs;
+  });
+  if (num_groups == 1 || stream_is_capturing(caller)) {
+    // nothing to overlap / a captured stream cannot fork into the engine's lanes: in order
+    for (int g : idx) {
+      const int rc = solve_joint(e, &batches[g], &inputs[g], &outputs[g], caller, nullptr, false);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  const int nl = std::min(num_groups, e->max_lanes);
+  for (int k = 0; k < nl; k++) {
+    const int rc = ensure_lane(e, k);
+    if (rc) return rc;
+  }
+  // this call uses the lanes' workspaces only, but an unpipelined solve that is still running on
+  // the caller's stream owns nothing of theirs: fork the lanes from the caller's position
+  HIPCHK(hipEventRecord(e->ev_fork, caller));
+  for (int k = 0; k < nl; k++) HIPCHK(hipStreamWaitEvent(e->lanes[k].stream, e->ev_fork, 0));
+  // The sampling/LP kernels of the groups run one after another in weight order, each with the
+  // whole machine to itself, so that the heaviest group's sweep -- whose longest path is the
+  // call's critical path -- starts as early as it can; the sweeps then overlap each other and the
+  // later groups' sampling/LP kernels (a lane's front stage waits for the previous lane's).
+  // (TPAMD_CHAIN_FRONTS, A/B: 0 no order among the front stages; 1 each behind the previous
+  // group's; 2 all behind the heaviest group's; 3 as 2, and no sweep starts before every front
+  // stage of the call is done -- for calls with at most one group per lane.)
+  int rc_all = 0;
+  hipEvent_t prev_front = nullptr;
+  const bool two_phase = e->chain_fronts == 3 && num_groups <= nl;
+  for (int n = 0; n < num_groups && rc_all == 0; n++) {
+    const int g = idx[n];
+    if (batches[g].num_paths <= 0) continue;
+    const int k = n % nl;
+    e->front_wait = e->chain_fronts ? prev_front : nullptr;
+    e->front_record = e->lanes[k].front;
+    e->phase = two_phase ? 1 : 0;
+    rc_all = with_lane_workspace(e, k, [&](hipStream_t st) {
+      return solve_joint(e, &batches[g], &inputs[g], &outputs[g], st, nullptr, false);
+    });
+    if (e->chain_fronts == 1 || prev_front == nullptr) prev_front = e->lanes[k].front;
+  }
+  e->front_wait = nullptr;
+  e->front_record = nullptr;
+  if (two_phase) {
+    for (int n = 0; n < num_groups; n++)
+      if (batches[idx[n]].num_paths > 0) e->back_wait.push_back(e->lanes[n % nl].front);
+    e->phase = 2;
+    for (int n = 0; n < num_groups && rc_all == 0; n++) {
+      const int g = idx[n];
+      if (batches[g].num_paths <= 0) continue;
+      rc_all = with_lane_workspace(e, n % nl, [&](hipStream_t st) {
+        return solve_joint(e, &batches[g], &inputs[g], &outputs[g], st, nullptr, false);
+      });
+    }
+    e->back_wait.clear();
+  }
+  e->phase = 0;
+  // join (also after an error: whatever was launched is ordered before the caller goes on)
+  for (int k = 0; k < nl; k++) {
+    HIPCHK(hipEventRecord(e->lanes[k].done, e->lanes[k].stream));
+    HIPCHK(hipStreamWaitEvent(caller, e->lanes[k].done, 0));
+  }
+  e->last_B = 0; e->last_N = 0; e->last_time = nullptr;   // no single "last solve" to query
+  return rc_all;
+}
+
+int tpamd_time_joint_groups_host(tpamd_engine *e, int num_groups, const tpamd_joint_batch *batches,
+                                 const tpamd_joint_inputs *inputs, const tpamd_path_outputs *outputs) {
+  if (!e || num_groups < 0 || (num_groups > 0 && (!batches || !inputs || !outputs)))
+    return TPAMD_E_INVALID_ARGUMENT;
+  std::vector<int> live;
+  for (int g = 0; g < num_groups; g++) {
+    if (batches[g].num_paths < 0) return TPAMD_E_INVALID_ARGUMENT;
+    if (batches[g].num_paths == 0) continue;
+    if (!joint_host_args_ok(&batches[g], &inputs[g], &outputs[g])) return TPAMD_E_INVALID_ARGUMENT;
+    live.push_back(g);
+  }
+  if (live.empty()) return 0;
+  TPAMD_ON_DEVICE(e);
+  const size_t G = live.size();
+  std::vector<JointStage> js(G);
   for (int pass = 0; pass < 2; pass++) {
     Stage s(pass ? e->stage_base : nullptr);
-    double *d_knots = s.take<double>(B * (P + 3)), *d_cp = s.take<double>(B * P * D);
-    double *d_vmax = s.take<double>(B * D), *d_amax = s.take<double>(B * D);
-    double *d_ps = s.take<double>(B), *d_dl = s.take<double>(B), *d_sd0 = s.take<double>(B);
-    double *d_sdd0 = s.take<double>(B), *d_t0 = s.take<double>(B);
-    double *d_t = s.take<double>(B * N), *d_s = s.take<double>(B * N);
-    double *d_sd = s.take<double>(B * N), *d_sdd = s.take<double>(B * N);
-    double *d_q = out->q ? s.take<double>(B * N * D) : nullptr;
-    double *d_qd = out->qd ? s.take<double>(B * N * D) : nullptr;
-    double *d_qdd = out->qdd ? s.take<double>(B * N * D) : nullptr;
-    int32_t *d_lei = s.take<int32_t>(B), *d_st = s.take<int32_t>(B);
-    double *d_dtm = s.take<double>(B);
-    double *d_sd2 = out->sd2 ? s.take<double>(B * N) : nullptr;
-    int32_t *d_ns = in->num_samples_per_path ? s.take<int32_t>(B) : nullptr;
+    for (size_t k = 0; k < G; k++) carve_joint_stage(s, &batches[live[k]], &inputs[live[k]], &outputs[live[k]], &js[k]);
     if (!pass) {
       int rc = ensure_stage(e, s.off);
       if (rc) return rc;
-      continue;
     }
-    hipStream_t st = nullptr;
-    if (d_ns) HIPCHK(hipMemcpyAsync(d_ns, in->num_samples_per_path, B * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_knots, in->knots, B * (P + 3) * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_cp, in->control_points, B * P * D * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_vmax, in->max_velocity, B * D * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_amax, in->max_acceleration, B * D * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_ps, in->path_start, B * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_dl, in->delta, B * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d_sd0, in->sd_start, B * 8, hipMemcpyHostToDevice, st));
-    if (in->sdd_start)
-      HIPCHK(hipMemcpyAsync(d_sdd0, in->sdd_start, B * 8, hipMemcpyHostToDevice, st));
-    else
-      HIPCHK(hipMemsetAsync(d_sdd0, 0, B * 8, st));
-    HIPCHK(hipMemcpyAsync(d_t0, in->time_start, B * 8, hipMemcpyHostToDevice, st));
-    tpamd_joint_inputs din{d_knots, d_cp, d_vmax, d_amax, d_ps, d_dl, d_sd0, d_sdd0, d_t0, d_ns};
-    tpamd_path_outputs dout{d_t, d_s, d_sd, d_sdd, d_q, d_qd, d_qdd, d_lei, d_dtm, d_st, d_sd2};
-    int rc = tpamd_time_joint_paths_device(e, bt, &din, &dout, st);
-    if (rc) return rc;
-    if (out->sd2) HIPCHK(hipMemcpyAsync(out->sd2, d_sd2, B * N * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out->time, d_t, B * N * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out->s, d_s, B * N * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out->sd, d_sd, B * N * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out->sdd, d_sdd, B * N * 8, hipMemcpyDeviceToHost, st));
-    if (out->q) HIPCHK(hipMemcpyAsync(out->q, d_q, B * N * D * 8, hipMemcpyDeviceToHost, st));
-    if (out->qd) HIPCHK(hipMemcpyAsync(out->qd, d_qd, B * N * D * 8, hipMemcpyDeviceToHost, st));
-    if (out->qdd) HIPCHK(hipMemcpyAsync(out->qdd, d_qdd, B * N * D * 8, hipMemcpyDeviceToHost, st));
-    if (out->last_extremal_index)
-      HIPCHK(hipMemcpyAsync(out->last_extremal_index, d_lei, B * 4, hipMemcpyDeviceToHost, st));
-    if (out->max_time_increment)
-      HIPCHK(hipMemcpyAsync(out->max_time_increment, d_dtm, B * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(out->status, d_st, B * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
   }
+  hipStream_t st = nullptr;
+  std::vector<tpamd_joint_batch> bts(G);
+  std::vector<tpamd_joint_inputs> dins(G);
+  std::vector<tpamd_path_outputs> douts(G);
+  for (size_t k = 0; k < G; k++) {
+    const JointStage &j = js[k];
+    int rc = upload_joint_stage(j, &batches[live[k]], &inputs[live[k]], st);
+    if (rc) return rc;
+    bts[k] = batches[live[k]];
+    dins[k] = tpamd_joint_inputs{j.knots, j.cp, j.vmax, j.amax, j.ps, j.dl, j.sd0, j.sdd0, j.t0, j.ns};
+    douts[k] = tpamd_path_outputs{j.t, j.s, j.sd, j.sdd, j.q, j.qd, j.qdd, j.lei, j.dtm, j.st, j.sd2};
+  }
+  int rc = tpamd_time_joint_groups_device(e, (int)G, bts.data(), dins.data(), douts.data(), st);
+  if (rc) return rc;
+  for (size_t k = 0; k < G; k++) {
+    rc = download_joint_stage(js[k], &batches[live[k]], &outputs[live[k]], st);
+    if (rc) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+int tpamd_time_joint_paths_host(tpamd_engine *e, const tpamd_joint_batch *bt,
+                                const tpamd_joint_inputs *in, const tpamd_path_outputs *out) {
+  if (!e || !bt || !in || !out) return TPAMD_E_INVALID_ARGUMENT;
+  if (bt->num_paths <= 0) return bt->num_paths == 0 ? 0 : TPAMD_E_INVALID_ARGUMENT;
+  if (!joint_host_args_ok(bt, in, out)) return TPAMD_E_INVALID_ARGUMENT;
+  TPAMD_ON_DEVICE(e);
+  JointStage j{};
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? e->stage_base : nullptr);
+    carve_joint_stage(s, bt, in, out, &j);
+    if (!pass) {
+      int rc = ensure_stage(e, s.off);
+      if (rc) return rc;
+    }
+  }
+  hipStream_t st = nullptr;
+  int rc = upload_joint_stage(j, bt, in, st);
+  if (rc) return rc;
+  tpamd_joint_inputs din{j.knots, j.cp, j.vmax, j.amax, j.ps, j.dl, j.sd0, j.sdd0, j.t0, j.ns};
+  tpamd_path_outputs dout{j.t, j.s, j.sd, j.sdd, j.q, j.qd, j.qdd, j.lei, j.dtm, j.st, j.sd2};
+  // never pipelined: the inputs were just queued on this stream, the outputs are copied back
+  // right behind the solve, and the staging buffer is reused by the next _host call
+  rc = solve_joint(e, bt, &din, &dout, st, nullptr, /*allow_pipelining=*/false);
+  if (rc) return rc;
+  rc = download_joint_stage(j, bt, out, st);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(st));
   return 0;
 }
 
@@ -1296,6 +1571,9 @@ int tpamd_query_device(tpamd_engine *e, int B, int N, int K, const double *time,
   }
   if (B == 0 || K == 0) return 0;
   TPAMD_ON_DEVICE(e);
+  // the engine's copy of sd2_ sits in the current workspace slot: its sweep may be running on an
+  // engine stream (mode 2), and the slot's next front stage must not overwrite it under this kernel
+  SlotGuard slot_guard(e, (hipStream_t)hip_stream, /*record_after=*/true, /*enable=*/sd2 == e->ws.sd2);
   const size_t total = (size_t)B * K;
   hipLaunchKernelGGL(k_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)hip_stream, B, N, K, time, s, sd, sd2, status, t_query, os,
@@ -1433,9 +1711,10 @@ int tpamd_debug_kernel_vgprs(tpamd_engine *e, int which) {
   if (!e || which < 0 || which > 1) return TPAMD_E_INVALID_ARGUMENT;
   TPAMD_ON_DEVICE(e);
   hipFuncAttributes attr;
-  const void *fn = which == 0 ? reinterpret_cast<const void *>(&k_sample_lp_joint<1, 7>)
-                              : reinterpret_cast<const void *>(&k_sweep_joint<7, 0>);
-  HIPCHK(hipFuncGetAttributes(&attr, fn));
+  if (which == 0)
+    HIPCHK(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&k_sample_lp_joint<1, 7>)));
+  else
+    HIPCHK((sweep_joint_attributes<7, 0>(&attr)));
   return attr.numRegs;
 }
 

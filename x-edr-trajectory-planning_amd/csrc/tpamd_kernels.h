@@ -26,6 +26,9 @@ struct Workspace {
   // Arrays keep the common stride N; only the first ns[b] samples of path b are used.
   const int32_t *ns;
   const double *amax;          // [B][D] joint acceleration limits (fused epilogue), or null
+  // Ragged batches: path handled by sweep workgroup k, longest path first (k_order_paths), so
+  // that the launch's tail is made of short paths; null: workgroup k handles path k.
+  const int32_t *order;
   double *lim;  // [B][2][C] lower then upper (joint mode)
   // per (path, sample)
   // joint mode: one record of R = 2D+2 doubles per sample,
@@ -48,6 +51,45 @@ struct Workspace {
 
 __device__ __forceinline__ int path_samples(const Workspace &ws, int b, int N) {
   return ws.ns ? min(ws.ns[b], N) : N;
+}
+__device__ __forceinline__ int path_of_block(const Workspace &ws, int block) {
+  return ws.order ? ws.order[block] : block;
+}
+
+// Longest-first processing order of a ragged batch: a counting sort of the paths by sample count
+// in bins of kOrderBin samples (the cost of a path's sweep grows with its sample count; inside a
+// bin the order does not matter). One block of 1024 threads; order[k] = path of workgroup k.
+// The hardware hands workgroups to the CUs in index order as slots free up, so a launch in this
+// order is a longest-processing-time-first schedule: the kernel no longer ends with a 4000-sample
+// path that started late on an otherwise idle machine.
+constexpr int kOrderBins = 1024;
+static __global__ void __launch_bounds__(1024) k_order_paths(int B, int N, const int32_t *ns, int32_t *order) {
+  __shared__ int hist[kOrderBins];
+  __shared__ int scan[kOrderBins];
+  const int tid = threadIdx.x;
+  const int shift = (N > 8192) ? 5 : 3;          // bins of 8 samples cover N <= 8192
+  hist[tid] = 0;
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    const int n = min(max(ns[b], 0), N);
+    atomicAdd(&hist[min((N - n) >> shift, kOrderBins - 1)], 1);
+  }
+  __syncthreads();
+  // exclusive prefix sum over the bins (Hillis-Steele, 10 rounds)
+  scan[tid] = hist[tid];
+  __syncthreads();
+  for (int off = 1; off < kOrderBins; off <<= 1) {
+    const int v = (tid >= off) ? scan[tid - off] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  hist[tid] = scan[tid] - hist[tid];              // first position of the bin
+  __syncthreads();
+  for (int b = tid; b < B; b += 1024) {
+    const int n = min(max(ns[b], 0), N);
+    order[atomicAdd(&hist[min((N - n) >> shift, kOrderBins - 1)], 1)] = b;
+  }
 }
 
 struct JointSource {
@@ -89,7 +131,7 @@ struct GenericSource {
 // (time_optimal_path_timing.cc:165-193, :554-576) plus the limit rows of
 // timeable_path_joint_spline.cc:327-339. s_end = path_start + delta*(N-1) as
 // path_timing_trajectory.cc:340-341.
-__global__ void k_setup_joint(int B, int N, int D, double safety, const double *vmax,
+static __global__ void k_setup_joint(int B, int N, int D, double safety, const double *vmax,
                               const double *amax, const double *path_start,
                               const double *delta, const double *sd_start,
                               const double *sdd_start, const double *t_start, Workspace ws) {
@@ -132,7 +174,7 @@ __global__ void k_setup_joint(int B, int N, int D, double safety, const double *
   ws.delta[b] = delta[b];
 }
 
-__global__ void k_setup_rows(int B, int N, const double *s_start, const double *s_end,
+static __global__ void k_setup_rows(int B, int N, const double *s_start, const double *s_end,
                              const double *sd_start, const double *sdd_start,
                              const double *t_start, Workspace ws) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,6 +229,8 @@ __device__ __forceinline__ void sample_lp_joint_body(int N, int D_rt, int P, con
   const int K = P + 3;
   const int D = DT ? DT : D_rt;
   const int C = 2 * D;
+  // a block that lies wholly behind the end of a (ragged) path has nothing to do
+  if ((int)(blockIdx.x * TPB) >= path_samples(ws, b, N)) return;
   double q1r[DT ? DT : 1], q2r[DT ? DT : 1];
   double *s_knots = lds;
   double *s_cp = s_knots + K;
@@ -291,7 +335,7 @@ k_sample_lp_joint_wide(int N, int D_rt, int P, const double *knots_g, const doub
 // Sampling only (TimeableJointSplinePath::SamplePath as a stand-alone call,
 // timeable_path_joint_spline.cc:294-318): q, q', q'' as [B][N][D] arrays.
 // grid = (ceil(N/TPB), B); dynamic LDS: knots[P+3] | control points [P][D].
-__global__ void k_sample_only(int N, int D, int P, const double *knots_g, const double *cps_g,
+static __global__ void k_sample_only(int N, int D, int P, const double *knots_g, const double *cps_g,
                               const double *path_start, const double *delta_g, double *q,
                               double *q1, double *q2) {
   extern __shared__ double lds[];
@@ -416,7 +460,7 @@ __device__ __forceinline__ Quat quat_power(Quat q, double power) {
 }
 
 // grid = (ceil(N/TPB), B); dynamic LDS: knots[P+3] | translation [P][3] | rotation [P][4]
-__global__ void k_sample_pose_splines(int N, int P, const double *knots_g, const double *trans_g,
+static __global__ void k_sample_pose_splines(int N, int P, const double *knots_g, const double *trans_g,
                                       const double *rot_g, const double *path_start,
                                       const double *delta_g, double *poses) {
   extern __shared__ double lds[];
@@ -468,7 +512,7 @@ __global__ void k_sample_pose_splines(int N, int P, const double *knots_g, const
 // Jacobians [B][N][6][D] are evaluated by the caller's jacobian_func_ (:576); J q' is
 // accumulated over the dofs in index order. Rows go to A/Bm/LO/HI [B][N][2D+2]; the
 // (q', q'') pairs go to the sample's record for k_epilogue.
-__global__ void k_cartesian_rows(int N, int D, double safety, const double *q_g,
+static __global__ void k_cartesian_rows(int N, int D, double safety, const double *q_g,
                                  const double *J_g, const double *vmax, const double *amax,
                                  const double *vtrans, const double *vrot, double *A,
                                  double *Bm, double *LO, double *HI, Workspace ws) {
@@ -516,7 +560,7 @@ __global__ void k_cartesian_rows(int N, int D, double safety, const double *q_g,
 // path_timing_trajectory.cc:340-341; the limit rows of
 // timeable_path_cartesian_spline.cc:559-592 (C = 2D+2 per path, constant along the path) and
 // the SetupProblem / IsSetupValid checks on them (time_optimal_path_timing.cc:174-175, :557).
-__global__ void k_setup_cartesian(int B, int N, int D, double safety, const double *vmax,
+static __global__ void k_setup_cartesian(int B, int N, int D, double safety, const double *vmax,
                                   const double *amax, const double *vtrans, const double *vrot,
                                   const double *path_start, const double *delta,
                                   const double *sd_start, const double *sdd_start,
@@ -745,7 +789,7 @@ __device__ __forceinline__ bool iso_at(const uint8_t *at, int N, int i) {
   return (i >= 1) && (i <= N - 2) && !at[i - 1] && at[i] && !at[i + 1];
 }
 
-__global__ void k_boundary_detect(int stride, Workspace ws) {
+static __global__ void k_boundary_detect(int stride, Workspace ws) {
   const int b = blockIdx.y;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = path_samples(ws, b, stride);
@@ -1444,7 +1488,7 @@ k_sweep(int stride, int max_loops, Source src, Workspace ws, double *t_out, doub
         double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
         int32_t *status_out) {
   extern __shared__ double lds[];
-  const int b = blockIdx.x;
+  const int b = path_of_block(ws, blockIdx.x);
   const int lane = threadIdx.x;
   const int N = path_samples(ws, b, stride);
   const size_t pb = (size_t)b * stride;
@@ -1510,7 +1554,7 @@ k_sweep(int stride, int max_loops, Source src, Workspace ws, double *t_out, doub
 // -------------------------------------------------------------- K3: epilogue
 // path_timing_trajectory.cc:458-472. One thread per (path, sample, joint): the reads of
 // the (q', q'') pairs and the writes of qd/qdd are contiguous across a wave.
-__global__ void k_epilogue(int B, int N, int D, const double *rec, const double *sd,
+static __global__ void k_epilogue(int B, int N, int D, const double *rec, const double *sd,
                            const double *sdd, const double *amax, const int32_t *status,
                            const int32_t *ns, double *qd, double *qdd) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1572,7 +1616,7 @@ enum { kPlanOk = 0, kPlanFailedPrecondition = 1, kPlanOutOfRange = 2, kPlanInval
        kPlanInternal = 4, kPlanDeadlineExceeded = 5 };
 
 // where the next window starts (path_timing_trajectory.cc:318-341)
-__global__ void k_plan_begin(PlanParams p, Workspace ws) {
+static __global__ void k_plan_begin(PlanParams p, Workspace ws) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.B) return;
   if (!p.active[b]) return;
@@ -1606,7 +1650,7 @@ __global__ void k_plan_begin(PlanParams p, Workspace ws) {
 }
 
 // skip marks for the planners that are not looping (after set-up wrote the error bits)
-__global__ void k_plan_mark_skipped(PlanParams p, Workspace ws) {
+static __global__ void k_plan_mark_skipped(PlanParams p, Workspace ws) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.B) return;
   if (!p.active[b]) ws.err_bits[b] |= kErrSkip;
@@ -1614,7 +1658,7 @@ __global__ void k_plan_mark_skipped(PlanParams p, Workspace ws) {
 
 // least-squares start velocity along the start tangent (path_timing_trajectory.cc:360-393),
 // after K1 has sampled the window: q'(0) is the first record's first components
-__global__ void k_plan_project(PlanParams p, Workspace ws) {
+static __global__ void k_plan_project(PlanParams p, Workspace ws) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.B) return;
   if (!p.active[b]) return;
@@ -1648,7 +1692,7 @@ __global__ void k_plan_project(PlanParams p, Workspace ws) {
 }
 
 // loop bookkeeping after a window (path_timing_trajectory.cc:639-660)
-__global__ void k_plan_end(PlanParams p) {
+static __global__ void k_plan_end(PlanParams p) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= p.B) return;
   p.append[b] = 0;
@@ -1674,7 +1718,7 @@ __global__ void k_plan_end(PlanParams p) {
 }
 
 // drop what the window replaces and append it (path_timing_trajectory.cc:418-472)
-__global__ void k_plan_append(PlanParams p) {
+static __global__ void k_plan_append(PlanParams p) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.N || !p.append[b]) return;
@@ -1695,7 +1739,7 @@ __global__ void k_plan_append(PlanParams p) {
 }
 
 // (q', q'') pairs of the records -> separate [B][N][D] arrays (GetFirst/SecondPathDerivativeAt)
-__global__ void k_unpack_records(int B, int N, int D, const double *rec, double *q1, double *q2) {
+static __global__ void k_unpack_records(int B, int N, int D, const double *rec, double *q1, double *q2) {
   const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (size_t)B * N * D) return;
   const size_t o = e / D;
@@ -1712,7 +1756,7 @@ __global__ void k_unpack_records(int B, int N, int D, const double *rec, double 
 // sd2_g: the squared velocities sd2_ of the SAME solve that produced time/s/sd. ds_, s_start
 // and s_end are recovered from the s row: s[0] = ds*0 + s_start and s[N-1] = s_end exactly
 // (.cc:540-547), so (s[N-1] - s[0]) / (N-1) repeats the operation that formed ds_ (.cc:540).
-__global__ void k_query(int B, int N, int K, const double *time, const double *s,
+static __global__ void k_query(int B, int N, int K, const double *time, const double *s,
                         const double *sd, const double *sd2_g, const int32_t *status,
                         const double *tq, double *os, double *osd, double *osdd,
                         int32_t *ok) {
@@ -1781,7 +1825,7 @@ struct ResampleParams {
 
 __device__ __forceinline__ double lerp_ref(double t, double a, double b) { return a + t * (b - a); }
 
-__global__ void k_resample(ResampleParams p) {
+static __global__ void k_resample(ResampleParams p) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = p.N, D = p.D;
@@ -1844,7 +1888,7 @@ __global__ void k_resample(ResampleParams p) {
 // interpolated output and the copies of the kept samples are done by all lanes.
 // p.time_step carries the minimum time delta to keep (0.95 time step, :893-900).
 // Dynamic LDS: int[N].
-__global__ void __launch_bounds__(64) k_resample_skip(ResampleParams p) {
+static __global__ void __launch_bounds__(64) k_resample_skip(ResampleParams p) {
   extern __shared__ int kept[];
   __shared__ int s_count, s_lower;
   const int b = blockIdx.x;

@@ -1296,7 +1296,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
 #ifndef TPAMD_BOUNDARY_FAST
 #define TPAMD_BOUNDARY_FAST 1
 #endif
-  // Paths of up to 2100 samples: passes 2 (second half), 3 and 4 from ONE round of loads, with no
+  // Passes 2 (second half), 3 and 4 from ONE round of loads per segment of 2108 samples, with no
   // load, branch or cross-lane operation inside the per-sample arithmetic. The path is cut into
   // chunks of 62 samples; a wave takes every other chunk and loads it with one sample of overlap
   // on either side (lane l of chunk c holds sample 62c + l - 1, lanes 1..62 own theirs), so a
@@ -1311,17 +1311,24 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
   // does not fit, take the general code below.
   const int slow_cap = ((N + 127) / 128) * 64 + 64;
   const int flag_bytes = (int)(ff_l - at_l);
-  if (TPAMD_BOUNDARY_FAST && N <= 62 * 2 * UF && 3 * flag_bytes + 8 * slow_cap <= 8 * N) {
+  // Paths of more than 2 x 17 chunks are handled segment by segment (the flags of a pass are
+  // complete for the whole path before the next pass reads them). Every pass loads its segment
+  // afresh: keeping the 51 registers of a one-segment path from the second pass to the third
+  // costs 24 VGPRs in the loop form (220 instead of 196: no room for the sampling/LP kernel beside
+  // two sweep waves), and the second round of loads hits the cache.
+  constexpr int kSegChunks = 2 * UF;
+  const int nseg = (N + 62 * kSegChunks - 1) / (62 * kSegChunks);
+  if (TPAMD_BOUNDARY_FAST && 3 * flag_bytes + 8 * slow_cap <= 8 * N) {
     int *slow = reinterpret_cast<int *>(at_l + 3 * flag_bytes) + w * slow_cap;
     int nslow = 0;
-    // the samples whose bit is set in `mask` (bit u: chunk 2u + w), appended to this wave's list
-    auto list_samples = [&](unsigned mask) {
+    // the samples whose bit is set in `mask` (bit u: chunk cb + 2u + w), appended to this wave's list
+    auto list_samples = [&](unsigned mask, int cb) {
 #pragma unroll
       for (int u = 0; u < UF; u++) {
         const bool need = (mask >> u) & 1u;
         const unsigned long long bm = __ballot(need);
         if (bm) {
-          if (need) slow[nslow + __popcll(bm & ((1ull << lane) - 1ull))] = 62 * (2 * u + w) + lane - 1;
+          if (need) slow[nslow + __popcll(bm & ((1ull << lane) - 1ull))] = 62 * (cb + 2 * u + w) + lane - 1;
           nslow += __popcll(bm);
         }
       }
@@ -1329,15 +1336,18 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
     // pass 2, first half (.cc:1386-1395): FindSddMax/Min at sd2_max_for_sdd0 next to isolated
     // points -- usually there are none, which one ballot per chunk establishes
     {
-      unsigned zf = 0u;
+      for (int seg = 0; seg < nseg; seg++) {
+        const int cb = seg * kSegChunks;
+        unsigned zf = 0u;
 #pragma unroll
-      for (int u = 0; u < UF; u++) {
-        const int j = 62 * (2 * u + w) + lane - 1;
-        const int jb = max(j, 1);
-        zf |= (unsigned)((lane >= 1) && (lane <= 62) && (j >= 0) && (j < N) &&
-                         ((iso_l[jb - 1] | iso_l[jb + 1]) != 0)) << u;
+        for (int u = 0; u < UF; u++) {
+          const int j = 62 * (cb + 2 * u + w) + lane - 1;
+          const int jb = max(j, 1);
+          zf |= (unsigned)((lane >= 1) && (lane <= 62) && (j >= 0) && (j < N) &&
+                           ((iso_l[jb - 1] | iso_l[jb + 1]) != 0)) << u;
+        }
+        list_samples(zf, cb);
       }
-      list_samples(zf);
       JointSweep<D, E>::wave_lds_sync();
       for (int e0 = 0; e0 < nslow; e0 += 64) {
         const bool valid = e0 + lane < nslow;
@@ -1396,18 +1406,23 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
     double m0c[UF], X0c[UF], Y0c[UF];
     // (indices stay affine in u wherever the chunk lies inside the path: one address register per
     // array and immediate offsets instead of 51 clamped addresses)
+    auto load_segment = [&](int cb) {
 #pragma unroll
-    for (int u = 0; u < UF; u++) {
-      const int c = 2 * u + w;
-      const int k = 62 * c + lane - 1;
-      const int kc = (c >= 1 && 62 * c + 62 < N) ? k : cl(k);        // (uniform choice)
-      m0c[u] = m0[kc]; X0c[u] = X0[kc]; Y0c[u] = Y0[kc];
-    }
+      for (int u = 0; u < UF; u++) {
+        const int c = cb + 2 * u + w;
+        const int k = 62 * c + lane - 1;
+        const int kc = (c >= 1 && 62 * c + 62 < N) ? k : cl(k);        // (uniform choice)
+        m0c[u] = m0[kc]; X0c[u] = X0[kc]; Y0c[u] = Y0[kc];
+      }
+    };
     const bool owner = (lane >= 1) && (lane <= 62);
-    unsigned listed = 0u;              // bit u: this lane's sample of chunk 2u + w goes to the list
+    for (int seg = 0; seg < nseg; seg++) {
+    const int cb = seg * kSegChunks;
+    load_segment(cb);
+    unsigned listed = 0u;              // bit u: this lane's sample of chunk cb + 2u + w goes to the list
 #pragma unroll
     for (int u = 0; u < UF; u++) {
-      const int k = 62 * (2 * u + w) + lane - 1;
+      const int k = 62 * (cb + 2 * u + w) + lane - 1;
       const bool inside = owner && (k >= 1) && (k <= N - 2);
       // unclamped byte reads: a byte from outside [0, N) can only send a sample to the list, which
       // is always right (the reads stay inside this LDS region; lane 0 of the first chunk reads
@@ -1429,8 +1444,9 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
       if (owner && k >= 0 && k < N && !to_list) ff_l[k] = 0;
       listed |= (unsigned)to_list << u;
     }
-    list_samples(listed);
+    list_samples(listed, cb);
     drain_detect();
+    }
     __threadfence_block();
     __syncthreads();
     TPAMD_ACC(21, tp0);
@@ -1485,10 +1501,13 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
       nslow = 0;
       JointSweep<D, E>::wave_lds_sync();
     };
-    listed = 0u;
+    for (int seg = 0; seg < nseg; seg++) {
+    const int cb = seg * kSegChunks;
+    load_segment(cb);
+    unsigned listed = 0u;
 #pragma unroll
     for (int u = 0; u < UF; u++) {
-      const int j = 62 * (2 * u + w) + lane - 1;
+      const int j = 62 * (cb + 2 * u + w) + lane - 1;
       const bool mine = owner && (j >= 0) && (j < N);
       const int jb = max(j, 1);
       // a deferred fix or an isolated point at j-1 .. j+2 (stray bytes only add list entries)
@@ -1498,8 +1517,9 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
       if (mine && !busy) P.finalize(j, m0c[u], X0c[u], Y0c[u], (j + 1 <= N - 1) ? m0r : 0.0);
       listed |= (unsigned)(mine && busy) << u;
     }
-    list_samples(listed);
+    list_samples(listed, cb);
     drain_final();
+    }
     P.template flush<true>(diag);
     __threadfence_block();
     __syncthreads();
@@ -1675,10 +1695,19 @@ __host__ __device__ inline size_t sweep_joint_lds_bytes(int N) {
 // the backward wave finishes with its share (emit_range); the tail is shared by the two waves.
 // TPAMD_SWEEP_WAVES_PER_EU (build-time, A/B): ask the compiler for a register budget that lets
 // that many waves share a SIMD (3 -> 168 VGPRs).
+// Wide records (D > 8) get the budget of ONE wave per SIMD: the 14-joint kernel needs 300
+// registers (256 + 44 in the accumulation half of the unified file) and spilled 184 bytes per
+// lane to scratch memory -- loads on the sequential chain -- when held to 256. At 304 allocated
+// registers one 7-joint sweep wave (196) or two sampling/LP waves still fit beside it on a SIMD.
 #ifndef TPAMD_SWEEP_WAVES_PER_EU
 #define TPAMD_SWEEP_WAVES_PER_EU 2
 #endif
-#define TPAMD_SWEEP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(TPAMD_SWEEP_WAVES_PER_EU, TPAMD_SWEEP_WAVES_PER_EU)))
+#ifndef TPAMD_SWEEP_WAVES_PER_EU_WIDE
+#define TPAMD_SWEEP_WAVES_PER_EU_WIDE 1
+#endif
+#define TPAMD_SWEEP_OCCUPANCY                                                                          \
+  __attribute__((amdgpu_waves_per_eu((D > 8) ? TPAMD_SWEEP_WAVES_PER_EU_WIDE : TPAMD_SWEEP_WAVES_PER_EU, \
+                                     (D > 8) ? TPAMD_SWEEP_WAVES_PER_EU_WIDE : TPAMD_SWEEP_WAVES_PER_EU)))
 template <int D, int E = 0>
 __global__ void __launch_bounds__(128) TPAMD_SWEEP_OCCUPANCY
 k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
@@ -1687,7 +1716,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   extern __shared__ double lds[];
   typedef JointSweep<D, E> JS;
   typedef SweepLds<D, E> LL;
-  const int b = blockIdx.x;
+  const int b = uniform_i32(path_of_block(ws, blockIdx.x));
   const int lane = threadIdx.x & 63;
   const int w = uniform_i32((int)(threadIdx.x >> 6));
   const int tid = threadIdx.x;
@@ -2253,7 +2282,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 //   ds   at ds_base   + r * shard_stride + b,   t_start likewise
 //   out  at t_out     + (r * paths_per_shard + b) * N
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 k_rebuild_time(int N, int paths_per_shard, size_t shard_stride, const double *sd_base,
                const double *ds_base, const double *t_start_base, const int32_t *ns, double *t_out) {
   const int p = blockIdx.x, lane = threadIdx.x;

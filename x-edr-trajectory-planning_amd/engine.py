@@ -14,7 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.environ.get("TPAMD_LIBRARY") or os.path.join(_CSRC, "libtpamd.so")   # override: A/B builds
-_SOURCES = ["tpamd_capi.hip", "tpamd_kernels.h", "tpamd_device.h", "tpamd_sweep_joint.h"]
+_SOURCES = ["tpamd_capi.hip", "tpamd_sweep_inst.hip", "tpamd_launch.h", "tpamd_kernels.h", "tpamd_device.h",
+            "tpamd_sweep_joint.h"]
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "tpamd.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
@@ -33,16 +34,44 @@ class TpamdError(RuntimeError):
     pass
 
 
+# (joint count, extra rows) instances of the specialised sweep kernel: one translation unit each
+# (csrc/tpamd_launch.h TPAMD_SWEEP_INSTANCES must list the same pairs)
+SWEEP_INSTANCES = [(3, 0), (4, 0), (5, 0), (6, 0), (7, 0), (8, 0), (14, 0), (6, 2), (7, 2)]
+
+
 def _compile(target, extra_flags, force, verbose):
+    """hipcc -c every translation unit (in parallel: the sweep instances take 10-18 s each), then
+    link. Objects are kept per target under build/ so that a rebuild recompiles everything only
+    when a source changed."""
     deps = [os.path.join(_CSRC, s) for s in _SOURCES] + [_HEADER]
     stale = force or not os.path.exists(target) or any(
         os.path.getmtime(d) > os.path.getmtime(target) for d in deps)
-    if stale:
-        cmd = (["hipcc"] + HIPCC_FLAGS + list(extra_flags) +
-               ["-o", target, os.path.join(_CSRC, "tpamd_capi.hip")])
+    if not stale:
+        return target
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(os.path.dirname(_HERE), "build",
+                          "obj_" + os.path.splitext(os.path.basename(target))[0])
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + list(extra_flags)
+    units = [(os.path.join(objdir, "capi.o"), ["tpamd_capi.hip"])]
+    for d, e in SWEEP_INSTANCES:
+        units.append((os.path.join(objdir, "sweep_%d_%d.o" % (d, e)),
+                      ["-DTPAMD_INST_D=%d" % d, "-DTPAMD_INST_E=%d" % e, "tpamd_sweep_inst.hip"]))
+
+    def one(unit):
+        obj, args = unit
+        cmd = ["hipcc"] + flags + ["-c", "-o", obj] + args[:-1] + [os.path.join(_CSRC, args[-1])]
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=_CSRC)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(one, units))
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=_CSRC)
     return target
 
 
@@ -124,6 +153,7 @@ ABI_SYMBOLS = [
     "tpamd_engine_workspace_bytes",
     "tpamd_time_joint_paths_device",
     "tpamd_time_joint_paths_host", "tpamd_sample_joint_paths_host",
+    "tpamd_time_joint_groups_device", "tpamd_time_joint_groups_host",
     "tpamd_optimize_rows_device", "tpamd_optimize_rows_host",
     "tpamd_time_cartesian_paths_device", "tpamd_time_cartesian_paths_host",
     "tpamd_sample_pose_splines_device", "tpamd_sample_pose_splines_host",
@@ -174,6 +204,12 @@ def load_library():
     L.tpamd_time_joint_paths_host.restype = i
     L.tpamd_time_joint_paths_host.argtypes = [vp, C.POINTER(_JointBatch),
                                               C.POINTER(_JointInputs), C.POINTER(_PathOutputs)]
+    L.tpamd_time_joint_groups_device.restype = i
+    L.tpamd_time_joint_groups_device.argtypes = [vp, i, C.POINTER(_JointBatch), C.POINTER(_JointInputs),
+                                                 C.POINTER(_PathOutputs), vp]
+    L.tpamd_time_joint_groups_host.restype = i
+    L.tpamd_time_joint_groups_host.argtypes = [vp, i, C.POINTER(_JointBatch), C.POINTER(_JointInputs),
+                                               C.POINTER(_PathOutputs)]
     L.tpamd_sample_joint_paths_host.restype = i
     L.tpamd_sample_joint_paths_host.argtypes = [vp, i, i, i, i] + [vp] * 7
     L.tpamd_optimize_rows_device.restype = i
@@ -308,6 +344,31 @@ class Engine:
             _check(self._lib.tpamd_time_joint_paths_device(self._h, C.byref(bt), C.byref(ji),
                                                            C.byref(po), _stream_ptr(stream)),
                    "tpamd_time_joint_paths_device")
+
+    def time_joint_groups(self, groups, stream=None, host=False):
+        """Several joint batches side by side (tpamd_time_joint_groups_*): `groups` is a list of
+        dicts with keys inputs, outputs, num_samples and optional safety, max_solver_loops -- each
+        what time_joint_paths takes."""
+        G = len(groups)
+        bts, jis, pos = (_JointBatch * G)(), (_JointInputs * G)(), (_PathOutputs * G)()
+        for g, grp in enumerate(groups):
+            cp = grp["inputs"]["control_points"]
+            B, P, D = cp.shape
+            bts[g] = _JointBatch(B, D, int(grp["num_samples"]), P, int(grp.get("max_solver_loops", 0)),
+                                 0, float(grp.get("safety", 0.8)))
+            jis[g] = _JointInputs(*[_ptr(grp["inputs"].get(k)) for k in (
+                "knots", "control_points", "max_velocity", "max_acceleration", "path_start", "delta",
+                "sd_start", "sdd_start", "time_start", "num_samples_per_path")])
+            pos[g] = _PathOutputs(*[_ptr(grp["outputs"].get(k)) for k in (
+                "time", "s", "sd", "sdd", "q", "qd", "qdd", "last_extremal_index",
+                "max_time_increment", "status", "sd2")])
+        if host:
+            _check(self._lib.tpamd_time_joint_groups_host(self._h, G, bts, jis, pos),
+                   "tpamd_time_joint_groups_host")
+        else:
+            _check(self._lib.tpamd_time_joint_groups_device(self._h, G, bts, jis, pos,
+                                                            _stream_ptr(stream)),
+                   "tpamd_time_joint_groups_device")
 
     def sample_joint_paths(self, knots, control_points, path_start, delta, num_samples):
         """Host numpy arrays -> (q, q1, q2) [B][N][D]."""
