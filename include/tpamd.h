@@ -61,6 +61,8 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out);
 void tpamd_engine_destroy(tpamd_engine *engine);
 int tpamd_version(void);
 const char *tpamd_error_string(int code);
+/* HIP devices visible to the library (0: none, the engine has no CPU fallback). */
+int tpamd_device_count(void);
 /* Pre-size the workspace for batches up to (num_paths, num_samples, num_rows). */
 int tpamd_engine_reserve(tpamd_engine *engine, int num_paths, int num_samples,
                          int num_rows);
@@ -367,6 +369,17 @@ int tpamd_rebuild_time_device(tpamd_engine *engine, int num_shards, int paths_pe
                               const double *ds, const double *time_start,
                               const int32_t *num_samples_per_path, double *time_out,
                               void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Sharding a batch of independent paths over several devices (the arithmetic of
+ * sharding.shard_bounds / balanced_bounds, which bench.py uses across processes): contiguous
+ * blocks of path indices, block k = [begin[k], begin[k+1]). begin has num_shards + 1 entries.
+ * tpamd_shard_bounds: sizes differ by at most one. tpamd_shard_bounds_balanced: blocks of roughly
+ * equal total cost for per-path costs (ragged batches: samples x rows^2), every block non-empty
+ * while paths last. Host arithmetic only (no device needed).
+ * ------------------------------------------------------------------------ */
+void tpamd_shard_bounds(int num_paths, int num_shards, int32_t *begin);
+void tpamd_shard_bounds_balanced(int num_paths, const double *cost, int num_shards, int32_t *begin);
 
 /* ------------------------------------------------------------------------
  * Uniform-in-time resample: PathTimingTrajectory::ResampleEquidistantlyInTime

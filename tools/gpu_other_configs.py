@@ -79,10 +79,12 @@ def cartesian_case(name, B, D, N, check=32):
                       "cpu_oracle_64_threads_paths_per_s": round(cpu, 1)}), flush=True)
 
 
-def mixed_case(name, per_group, check=8, bucket=512):
+def mixed_case(name, per_group, check=8, bucket=0):
     """3 x per_group paths of 6/7/14 joints, 500..4000 samples each. Timed two ways: the DOF groups
-    one after another at their common stride (how round 2 ran it), and bucketed by
-    (D, ceil(N / bucket)) with all buckets side by side (tpamd_time_joint_groups_device)."""
+    one after another at their common stride (how round 2 ran it), and as groups side by side
+    (tpamd_time_joint_groups_device): one group per joint count (bucket = 0, the fastest: 1.52 ms),
+    or bucketed by (D, ceil(N / bucket)) -- measured slower the finer the buckets (TPAMD_BUCKET=2560:
+    1.93 ms, 512: 3.7 ms; every bucket costs four launches and the runtime has four hardware queues)."""
     rng = np.random.default_rng(11)
     groups, buckets = [], []
     for D in (6, 7, 14):
@@ -167,4 +169,4 @@ if __name__ == "__main__":
         cartesian_case("configs[3] 4096 x 6-DOF Cartesian x 2000", 4096, 6, 2000)
     if "4" in cases:
         mixed_case("configs[4] one-GPU share: 3 x 512 paths, 6/7/14-DOF, ragged", 512,
-                   bucket=int(os.environ.get("TPAMD_BUCKET", "512")))
+                   bucket=int(os.environ.get("TPAMD_BUCKET", "0")))

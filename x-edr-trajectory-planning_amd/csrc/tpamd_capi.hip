@@ -471,6 +471,40 @@ const char *tpamd_error_string(int code) {
   }
 }
 
+int tpamd_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 0) return 0;
+  return count;
+}
+
+void tpamd_shard_bounds(int num_paths, int num_shards, int32_t *begin) {
+  if (!begin || num_shards <= 0) return;
+  const int total = num_paths > 0 ? num_paths : 0;
+  const int base = total / num_shards, rem = total % num_shards;
+  for (int r = 0; r <= num_shards; r++) begin[r] = r * base + (r < rem ? r : rem);
+}
+
+void tpamd_shard_bounds_balanced(int num_paths, const double *cost, int num_shards, int32_t *begin) {
+  if (!begin || num_shards <= 0) return;
+  const int n = (num_paths > 0 && cost) ? num_paths : 0;
+  double total = 0.0;
+  for (int i = 0; i < n; i++) total += cost[i];
+  int k = 1, lo = 0;
+  double acc = 0.0;
+  begin[0] = 0;
+  for (int i = 0; i < n; i++) {
+    acc += cost[i];
+    const int remaining_items = n - (i + 1), remaining_blocks = num_shards - k;
+    if (k < num_shards && (acc >= total * k / num_shards || remaining_items == remaining_blocks)) {
+      begin[k] = i + 1;
+      lo = i + 1;
+      k++;
+    }
+  }
+  (void)lo;
+  for (; k <= num_shards; k++) begin[k] = n;
+}
+
 int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
   if (!out) return TPAMD_E_INVALID_ARGUMENT;
   *out = nullptr;

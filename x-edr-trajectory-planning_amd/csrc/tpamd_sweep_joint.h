@@ -31,6 +31,8 @@
 // the reference's; results are bit-identical.
 #pragma once
 
+#include <type_traits>
+
 #include "tpamd_kernels.h"
 
 namespace tpamd {
@@ -1312,13 +1314,18 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
   const int slow_cap = ((N + 127) / 128) * 64 + 64;
   const int flag_bytes = (int)(ff_l - at_l);
   // Paths of more than 2 x 17 chunks are handled segment by segment (the flags of a pass are
-  // complete for the whole path before the next pass reads them). Every pass loads its segment
-  // afresh: keeping the 51 registers of a one-segment path from the second pass to the third
-  // costs 24 VGPRs in the loop form (220 instead of 196: no room for the sampling/LP kernel beside
-  // two sweep waves), and the second round of loads hits the cache.
+  // complete for the whole path before the next pass reads them), every pass loading its segment
+  // afresh. A path of one segment keeps the 51 registers from the second pass to the third; doing
+  // that inside the segment loops costs 24 VGPRs (220 instead of 196: no room for the sampling/LP
+  // kernel beside two sweep waves), so the one-segment form is compiled separately.
   constexpr int kSegChunks = 2 * UF;
   const int nseg = (N + 62 * kSegChunks - 1) / (62 * kSegChunks);
   if (TPAMD_BOUNDARY_FAST && 3 * flag_bytes + 8 * slow_cap <= 8 * N) {
+    // kOne: the path is one segment (N <= 2108) -- the segment loops fold away and the registers of
+    // the second pass serve the third, as before the segments existed; both forms are compiled.
+    auto fast_form = [&](auto one_segment) {
+    constexpr bool kOne = decltype(one_segment)::value;
+    const int nsg = kOne ? 1 : nseg;
     int *slow = reinterpret_cast<int *>(at_l + 3 * flag_bytes) + w * slow_cap;
     int nslow = 0;
     // the samples whose bit is set in `mask` (bit u: chunk cb + 2u + w), appended to this wave's list
@@ -1336,7 +1343,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
     // pass 2, first half (.cc:1386-1395): FindSddMax/Min at sd2_max_for_sdd0 next to isolated
     // points -- usually there are none, which one ballot per chunk establishes
     {
-      for (int seg = 0; seg < nseg; seg++) {
+      for (int seg = 0; seg < nsg; seg++) {
         const int cb = seg * kSegChunks;
         unsigned zf = 0u;
 #pragma unroll
@@ -1416,7 +1423,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
       }
     };
     const bool owner = (lane >= 1) && (lane <= 62);
-    for (int seg = 0; seg < nseg; seg++) {
+    for (int seg = 0; seg < nsg; seg++) {
     const int cb = seg * kSegChunks;
     load_segment(cb);
     unsigned listed = 0u;              // bit u: this lane's sample of chunk cb + 2u + w goes to the list
@@ -1501,9 +1508,9 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
       nslow = 0;
       JointSweep<D, E>::wave_lds_sync();
     };
-    for (int seg = 0; seg < nseg; seg++) {
+    for (int seg = 0; seg < nsg; seg++) {
     const int cb = seg * kSegChunks;
-    load_segment(cb);
+    if (!kOne) load_segment(cb);
     unsigned listed = 0u;
 #pragma unroll
     for (int u = 0; u < UF; u++) {
@@ -1524,6 +1531,9 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
     __threadfence_block();
     __syncthreads();
     TPAMD_ACC(22, tp0);
+    };
+    if (nseg == 1) fast_form(std::true_type{});
+    else fast_form(std::false_type{});
     return;
   }
 

@@ -83,6 +83,25 @@ def build_library(force=False, verbose=False, extra_flags=(), output=None):
     return _compile(_SO, extra_flags, force, verbose)
 
 
+MULTI_SO = os.path.join(_CSRC, "libtpamd_multi.so")
+
+
+def build_multi_library(force=False, verbose=False):
+    """libtpamd_multi.so (include/tpamd_multi.h): several devices from one process, on top of
+    libtpamd.so and RCCL. Host code only."""
+    src = os.path.join(_CSRC, "tpamd_multi.cc")
+    deps = [src, _HEADER, os.path.join(os.path.dirname(_HEADER), "tpamd_multi.h"), _SO]
+    if force or not os.path.exists(MULTI_SO) or any(
+            os.path.getmtime(d) > os.path.getmtime(MULTI_SO) for d in deps if os.path.exists(d)):
+        cmd = ["hipcc", "-O2", "-fPIC", "-shared", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", src,
+               "-o", MULTI_SO, "-L" + _CSRC, "-ltpamd", "-L/opt/rocm/lib", "-lrccl", "-lpthread",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=_CSRC)
+    return MULTI_SO
+
+
 DIAG_SO = os.path.join(_CSRC, "libtpamd_diag.so")
 
 
@@ -149,6 +168,7 @@ _LIB = None
 # every symbol include/tpamd.h declares
 ABI_SYMBOLS = [
     "tpamd_engine_create", "tpamd_engine_destroy", "tpamd_version", "tpamd_error_string",
+    "tpamd_device_count", "tpamd_shard_bounds", "tpamd_shard_bounds_balanced",
     "tpamd_engine_reserve", "tpamd_engine_set_pipelining", "tpamd_engine_fence",
     "tpamd_engine_workspace_bytes",
     "tpamd_time_joint_paths_device",
@@ -189,6 +209,11 @@ def load_library():
     L.tpamd_version.restype = i
     L.tpamd_error_string.restype = C.c_char_p
     L.tpamd_error_string.argtypes = [i]
+    L.tpamd_device_count.restype = i
+    L.tpamd_shard_bounds.restype = None
+    L.tpamd_shard_bounds.argtypes = [i, i, vp]
+    L.tpamd_shard_bounds_balanced.restype = None
+    L.tpamd_shard_bounds_balanced.argtypes = [i, vp, i, vp]
     L.tpamd_engine_reserve.restype = i
     L.tpamd_engine_reserve.argtypes = [vp, i, i, i]
     L.tpamd_engine_set_pipelining.restype = i

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <map>
+#include <thread>
 #include <tuple>
 
 #include "engine_handle.h"
@@ -28,16 +29,25 @@ Status BatchCartesianTiming::SetPaths(std::vector<CartesianPathSamples> paths) {
   return OkStatus();
 }
 
+Status BatchCartesianTiming::SetDevices(const std::vector<int> &devices) {
+  const int visible = ::tpamd::device_count();
+  for (size_t i = 0; i < devices.size(); i++) {
+    if (devices[i] < 0 || devices[i] >= visible) return InvalidArgumentError("no such device");
+    for (size_t j = 0; j < i; j++)
+      if (devices[j] == devices[i]) return InvalidArgumentError("device listed twice");
+  }
+  devices_ = devices;
+  return OkStatus();
+}
+
 Status BatchCartesianTiming::ComputeTimingProfiles(double time_start_sec, BatchTimingResult *r) {
   if (paths_.empty()) return InvalidArgumentError("SetPaths first");
-  tpamd_engine *engine = ::tpamd::shared_engine();
-  if (!engine) return InternalError("no GPU engine");
   const size_t Bt = paths_.size();
   r->status.assign(Bt, -1); r->last_extremal_index.assign(Bt, 0);
   r->samples_per_path.resize(Bt); r->dofs_per_path.resize(Bt);
   r->sample_offset.assign(Bt + 1, 0); r->joint_offset.assign(Bt + 1, 0);
   r->num_samples = 0; r->num_dofs = 0;
-  std::map<std::tuple<size_t, size_t, double>, std::vector<size_t>> groups;
+  std::vector<double> cost(Bt);
   for (size_t b = 0; b < Bt; b++) {
     const size_t n = paths_[b].ik_positions.size(), d = paths_[b].ik_positions[0].size();
     r->samples_per_path[b] = (int32_t)n; r->dofs_per_path[b] = (int32_t)d;
@@ -45,11 +55,36 @@ Status BatchCartesianTiming::ComputeTimingProfiles(double time_start_sec, BatchT
     r->joint_offset[b + 1] = r->joint_offset[b] + n * d;
     r->num_samples = std::max(r->num_samples, (int)n);
     r->num_dofs = std::max(r->num_dofs, (int)d);
-    groups[std::make_tuple(d, n, paths_[b].constraint_safety)].push_back(b);
+    cost[b] = (double)n * (2.0 * d + 2.0) * (2.0 * d + 2.0);
   }
   r->time.resize(r->sample_offset[Bt]); r->s.resize(r->sample_offset[Bt]);
   r->sd.resize(r->sample_offset[Bt]); r->sdd.resize(r->sample_offset[Bt]);
   r->q.resize(r->joint_offset[Bt]); r->qd.resize(r->joint_offset[Bt]); r->qdd.resize(r->joint_offset[Bt]);
+  const std::vector<int> devices = devices_.empty() ? std::vector<int>{::tpamd::default_device()} : devices_;
+  const int nd = (int)devices.size();
+  std::vector<int32_t> begin(nd + 1);
+  tpamd_shard_bounds_balanced((int)Bt, cost.data(), nd, begin.data());
+  std::vector<Status> st(nd, OkStatus());
+  std::vector<std::thread> threads;
+  for (int k = 1; k < nd; k++)
+    threads.emplace_back([&, k] { st[k] = ComputeBlock(devices[k], begin[k], begin[k + 1], time_start_sec, r); });
+  st[0] = ComputeBlock(devices[0], begin[0], begin[1], time_start_sec, r);
+  for (auto &t : threads) t.join();
+  for (const Status &s : st)
+    if (!s.ok()) return s;
+  return OkStatus();
+}
+
+Status BatchCartesianTiming::ComputeBlock(int device, size_t lo, size_t hi, double time_start_sec,
+                                          BatchTimingResult *r) const {
+  if (hi <= lo) return OkStatus();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine(device);
+  tpamd_engine *engine = lease.get();
+  if (!engine) return InternalError("no GPU engine");
+  std::map<std::tuple<size_t, size_t, double>, std::vector<size_t>> groups;
+  for (size_t b = lo; b < hi; b++)
+    groups[std::make_tuple(paths_[b].ik_positions[0].size(), paths_[b].ik_positions.size(),
+                           paths_[b].constraint_safety)].push_back(b);
 
   for (const auto &kv : groups) {
     const std::vector<size_t> &ids = kv.second;
@@ -79,7 +114,6 @@ Status BatchCartesianTiming::ComputeTimingProfiles(double time_start_sec, BatchT
     tpamd_path_outputs out{time.data(), s.data(), sd.data(), sdd.data(), nullptr, qd.data(), qdd.data(),
                            lei.data(), nullptr, status.data(), nullptr};
     {
-      ::tpamd::EngineGuard guard;
       const int rc = tpamd_time_cartesian_paths_host(engine, &batch, &in, &out);
       if (rc != 0) return InternalError(tpamd_error_string(rc));
     }

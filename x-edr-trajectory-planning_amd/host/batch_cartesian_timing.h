@@ -38,11 +38,18 @@ class BatchCartesianTiming {
   // Paths may differ in joint count and sample count; they are grouped by
   // (dofs, samples, constraint safety), one engine call per group.
   Status SetPaths(std::vector<CartesianPathSamples> paths);
+  // HIP devices that share the batch: contiguous blocks of roughly equal cost (samples x rows^2),
+  // one engine from the pool and one host thread per device (the Jacobian callbacks of a block run
+  // on its thread: they must be callable concurrently for different paths). Default: the default
+  // device alone.
+  Status SetDevices(const std::vector<int> &devices);
   // Results in the packed layout of BatchTimingResult; q holds the IK positions.
   Status ComputeTimingProfiles(double time_start_sec, BatchTimingResult *result);
 
  private:
+  Status ComputeBlock(int device, size_t lo, size_t hi, double time_start_sec, BatchTimingResult *r) const;
   std::vector<CartesianPathSamples> paths_;
+  std::vector<int> devices_;
 };
 
 }  // namespace trajectory_planning

@@ -30,14 +30,28 @@ struct BatchTimingResult {
 class BatchPathTiming {
  public:
   // Paths may differ in num_dofs, num_path_samples and waypoint count (BASELINE.json configs[4]):
-  // they are grouped by (dofs, control points, constraint safety), one engine call per group with
-  // per-path sample counts.
+  // they are grouped by (dofs, control points, constraint safety[, ceil(samples / bucket)]) with
+  // per-path sample counts, and ALL groups of a device are solved by one engine call, side by side
+  // (tpamd_time_joint_groups_host; within a group the sweep takes the paths longest first).
   Status SetPaths(const std::vector<std::shared_ptr<TimeableJointSplinePath>> &paths);
+  // HIP devices that share the batch: the paths are cut into contiguous blocks of
+  // roughly equal cost (samples x rows^2, tpamd_shard_bounds_balanced), one block, one engine from
+  // the pool and one host thread per device; results go straight into the caller's result, nothing
+  // travels between devices. Default: the default device (TPAMD_DEVICE, else 0) alone.
+  Status SetDevices(const std::vector<int> &devices);
+  // Sample-count bucket of ragged batches: 0 (default) = one group per (dofs, control points,
+  // safety), its stride the largest sample count; w > 0 = also by ceil(samples / w), as
+  // SURVEY.md 8d sketches with w = 512. Measured on MI355X (DESIGN.md, configs[4]): the coarser
+  // the faster -- every group costs four launches and the runtime has four hardware queues.
+  void SetSampleBucket(int samples) { sample_bucket_ = samples > 0 ? samples : 0; }
   // Times every path starting at path parameter 0 and time `time_start_sec`.
   Status ComputeTimingProfiles(double time_start_sec, BatchTimingResult *result);
 
  private:
+  Status ComputeBlock(int device, size_t lo, size_t hi, double time_start_sec, BatchTimingResult *r) const;
   std::vector<std::shared_ptr<TimeableJointSplinePath>> paths_;
+  std::vector<int> devices_;
+  int sample_bucket_ = 0;
 };
 
 }  // namespace trajectory_planning

@@ -177,7 +177,8 @@ Status PathTimingTrajectory::ProjectStartVelocity(const Window &w) {
 void PathTimingTrajectory::PlanJointWindowsOnDevice(const std::vector<PathTimingTrajectory *> &planners,
                                                     const std::vector<size_t> &ids, Time start,
                                                     Duration time_horizon, std::vector<Status> *status) {
-  tpamd_engine *engine = ::tpamd::shared_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  tpamd_engine *engine = lease.get();
   if (!engine) {
     for (size_t id : ids) (*status)[id] = InternalError("no GPU engine");
     return;
@@ -286,7 +287,6 @@ void PathTimingTrajectory::PlanJointWindowsOnDevice(const std::vector<PathTiming
     a.looping = looping.data();
     int rc;
     {
-      ::tpamd::EngineGuard guard;
       rc = tpamd_plan_joint_windows_host(engine, &a);
     }
     if (rc != 0) {
@@ -613,7 +613,8 @@ Status PathTimingTrajectory::ResampleEquidistantlyInTime(double start_sec) {
   const double duration = time_at_path_samples_.back() - start_sec;
   const int M = (int)(std::ceil(duration / time_step_sec_) + 1);
   if (M < 1) return InternalError("negative trajectory duration");
-  tpamd_engine *engine = ::tpamd::shared_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  tpamd_engine *engine = lease.get();
   if (!engine) return InternalError("no GPU engine");
   std::vector<double> ot(M), os(M), osd(M), osdd(M), oq((size_t)M * D), oqd((size_t)M * D), oqdd((size_t)M * D);
   int32_t count = 0;
@@ -628,7 +629,6 @@ Status PathTimingTrajectory::ResampleEquidistantlyInTime(double start_sec) {
   a.out_time = ot.data(); a.out_s = os.data(); a.out_sd = osd.data(); a.out_sdd = osdd.data();
   a.out_q = oq.data(); a.out_qd = oqd.data(); a.out_qdd = oqdd.data(); a.count = &count;
   {
-    ::tpamd::EngineGuard guard;
     const int rc = tpamd_resample_uniform_host(engine, &a);
     if (rc != 0) return InternalError(tpamd_error_string(rc));
   }
@@ -652,7 +652,8 @@ void PathTimingTrajectory::ResampleSkippingSamplesCloserThanTimeStep(double star
   const int S = (int)time_at_path_samples_.size();
   time_.clear(); positions_.clear(); velocities_.clear(); accelerations_.clear();
   path_parameter_.clear(); path_parameter_derivative_.clear(); second_path_parameter_derivative_.clear();
-  tpamd_engine *engine = ::tpamd::shared_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  tpamd_engine *engine = lease.get();
   if (!engine || S < 2) return;
   const int cap = S + 1;
   std::vector<double> ot(cap), os(cap), osd(cap), osdd(cap), oq((size_t)cap * D), oqd((size_t)cap * D),
@@ -669,7 +670,6 @@ void PathTimingTrajectory::ResampleSkippingSamplesCloserThanTimeStep(double star
   a.out_time = ot.data(); a.out_s = os.data(); a.out_sd = osd.data(); a.out_sdd = osdd.data();
   a.out_q = oq.data(); a.out_qd = oqd.data(); a.out_qdd = oqdd.data(); a.count = &count;
   {
-    ::tpamd::EngineGuard guard;
     if (tpamd_resample_skip_host(engine, &a) != 0) return;
   }
   const int M = std::min<int>(count, cap);

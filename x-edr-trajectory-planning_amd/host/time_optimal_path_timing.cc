@@ -78,9 +78,9 @@ bool TimeOptimalPathProfile::OptimizePathParameter() {
     LogError("Error, problem not defined/set up.");
     return false;
   }
-  tpamd_engine *engine = ::tpamd::shared_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  tpamd_engine *engine = lease.get();
   if (!engine) return false;
-  ::tpamd::EngineGuard guard;
   tpamd_rows_batch batch{1, num_samples_, num_constraints_, max_num_loops_};
   tpamd_rows_inputs in{rows_a_.data(), rows_b_.data(), rows_lo_.data(), rows_hi_.data(),
                        &s_start_, &s_end_, &sd_start_, &sdd_start_, &time_start_};
@@ -298,9 +298,9 @@ void TimeOptimalPathProfile::FindMaxSd2BruteForce(const Constraint &constr, Scal
 
 void TimeOptimalPathProfile::FindMaxSd2Simplex(const Constraint &constr, Scalar *sd2max,
                                                Scalar *sddmax, Scalar *sd2zero) {
-  tpamd_engine *engine = ::tpamd::shared_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  tpamd_engine *engine = lease.get();
   if (!engine) { *sd2max = *sddmax = *sd2zero = std::numeric_limits<Scalar>::quiet_NaN(); return; }
-  ::tpamd::EngineGuard guard;
   tpamd_find_max_sd2_host(engine, 1, constr.size(), constr.a_coefficient(), constr.b_coefficient(),
                           constr.lower(), constr.upper(), sd2max, sddmax, sd2zero);
 }

@@ -202,13 +202,13 @@ void TimeableJointSplinePath::AdoptSamples(double path_start, const double *q, c
 
 Status TimeableJointSplinePath::SamplePath(const double path_start) {
   if (knots_.empty()) return ::tpamd::compat::FailedPreconditionError("Call SetWaypoints first.");
-  tpamd_engine *engine = ::tpamd::shared_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  tpamd_engine *engine = lease.get();
   if (!engine) return InternalError("no GPU engine");
   const size_t N = options_.num_path_samples(), D = options_.num_dofs();
   std::vector<double> q(N * D), q1(N * D), q2(N * D);
   const double delta = options_.delta_parameter();
   {
-    ::tpamd::EngineGuard guard;
     const int rc = tpamd_sample_joint_paths_host(engine, 1, (int)D, (int)N, num_control_points(),
                                                  knots_.data(), packed_control_points_.data(),
                                                  &path_start, &delta, q.data(), q1.data(), q2.data());
