@@ -283,6 +283,11 @@ void tpo_planner_set_initial_velocity(tpo_planner *p, const double *v);
  * after SwitchToWaypointPath) */
 void tpo_planner_set_spline(tpo_planner *p, const double *knots, int num_knots, const double *cps,
                             int num_points, int state);
+/* instead of a spline: the IK table of a TimeableCartesianSplinePath (tp_oracle_plan.c):
+ * ik_positions [M][D] at parameters 0, delta, 2 delta, ..., jacobians [M][6][D] row-major */
+void tpo_planner_set_ik_table(tpo_planner *p, const double *ik_positions, const double *jacobians,
+                              int num_table_samples, double path_end, double max_trans_vel,
+                              double max_rot_vel, int state);
 int tpo_planner_plan(tpo_planner *p, int64_t start_ns, int64_t time_horizon_ns);
 int tpo_planner_num_samples(const tpo_planner *p);
 const double *tpo_planner_time(const tpo_planner *p);

@@ -70,6 +70,11 @@ struct tpo_planner {
   int num_points, num_knots;
   double *knots, *cps, *vmax, *amax, *initial_velocity;
   double *q, *q1, *q2; /* last SamplePath */
+  /* path (TimeableCartesianSplinePath after its IK callback): the IK solution at every multiple
+   * of delta along the whole path and the Jacobian there; see tpo_planner_set_ik_table */
+  int table_len;
+  double *table_q, *table_J, table_end;
+  double max_trans_vel, max_rot_vel;
   /* planner state (path_timing_trajectory.h members) */
   int initial_plan, planned_to_end, target_reached;
   double path_time_start, path_start, path_start_velocity, path_start_acceleration, path_horizon;
@@ -113,6 +118,7 @@ tpo_planner *tpo_planner_create(int D, int N, double delta, double safety, int64
 void tpo_planner_destroy(tpo_planner *p) {
   if (!p) return;
   free(p->knots); free(p->cps); free(p->vmax); free(p->amax); free(p->initial_velocity); free(p->q);
+  free(p->table_q); free(p->table_J);
   dv_free(&p->t_ps); dv_free(&p->s_ps); dv_free(&p->sd_ps); dv_free(&p->sdd_ps);
   dv_free(&p->q_ps); dv_free(&p->qd_ps); dv_free(&p->qdd_ps);
   dv_free(&p->time); dv_free(&p->s); dv_free(&p->sd); dv_free(&p->sdd);
@@ -143,9 +149,35 @@ void tpo_planner_set_spline(tpo_planner *p, const double *knots, int num_knots, 
   p->path_state = state;
 }
 
-/* timeable_path_joint_spline.cc:142-144 */
+/* What a TimeableCartesianSplinePath holds once its path-IK callback has run over the whole
+ * path (timeable_path_cartesian_spline.cc:484-538: path_ik_positions_, one sample per multiple of
+ * delta_parameter, PathIkIndex = round(parameter / delta) :671-674) plus the Jacobian the
+ * Jacobian callback returns at each of them (:576) and the Cartesian velocity limits. The IK and
+ * Jacobian callbacks are user code; the planner then does arithmetic only: SamplePath copies a
+ * segment of the table and differentiates it (:39-68, :527-542), ConstraintSetup adds the two
+ * Cartesian rows (:551-595). path_end = knots.back() (CloseToEnd :411-413). */
+void tpo_planner_set_ik_table(tpo_planner *p, const double *ik_positions, const double *jacobians,
+                              int num_table_samples, double path_end, double max_trans_vel,
+                              double max_rot_vel, int state) {
+  const size_t D = (size_t)p->D;
+  free(p->table_q); free(p->table_J);
+  p->table_q = (double *)malloc(sizeof(double) * (size_t)num_table_samples * D);
+  p->table_J = (double *)malloc(sizeof(double) * (size_t)num_table_samples * 6 * D);
+  memcpy(p->table_q, ik_positions, sizeof(double) * (size_t)num_table_samples * D);
+  memcpy(p->table_J, jacobians, sizeof(double) * (size_t)num_table_samples * 6 * D);
+  p->table_len = num_table_samples;
+  p->table_end = path_end;
+  p->max_trans_vel = max_trans_vel;
+  p->max_rot_vel = max_rot_vel;
+  p->path_state = state;
+  tpo_profile_destroy(p->profile);
+  p->profile = tpo_profile_create(p->N, 2 * p->D + 2);
+}
+
+/* timeable_path_joint_spline.cc:142-144 / timeable_path_cartesian_spline.cc:411-413 */
 static int close_to_end(const tpo_planner *p, double parameter) {
   const double kSmall = 1e-4;
+  if (p->table_q) return parameter >= p->table_end - kSmall;
   return p->num_knots == 0 || parameter >= p->knots[p->num_knots - 1] - kSmall;
 }
 
@@ -243,7 +275,7 @@ static void erase_trajectory_before(tpo_planner *p, int64_t time) {
 static int compute_timing_profile(tpo_planner *p, int64_t start, int64_t target_duration) {
   const double start_sec = time_to_sec(start);
   const int D = p->D, N = p->N;
-  if (p->knots == NULL) return TPO_PLAN_FAILED_PRECONDITION;
+  if (p->knots == NULL && p->table_q == NULL) return TPO_PLAN_FAILED_PRECONDITION;
   if (target_duration <= 0) return TPO_PLAN_INVALID_ARGUMENT;
   const int old_state = p->path_state;
   int offset = 0;
@@ -268,14 +300,30 @@ static int compute_timing_profile(tpo_planner *p, int64_t start, int64_t target_
     p->path_time_start = p->t_ps.v[offset];
   }
   p->path_horizon = p->path_start + p->delta * (N - 1);
-  if (tpo_joint_sample_path(p->knots, p->num_knots, p->cps, p->num_points, D, p->path_start, p->delta,
-                            N, p->q, p->q1, p->q2) != 0)
-    return TPO_PLAN_INTERNAL;
-  p->path_state = TPO_PATH_SAMPLED;
-  const int C = 2 * D;
+  const int C = p->table_q ? 2 * D + 2 : 2 * D;
   double *rows = (double *)malloc(sizeof(double) * 4 * (size_t)N * C);
   double *A = rows, *B = A + (size_t)N * C, *lo_ = B + (size_t)N * C, *hi_ = lo_ + (size_t)N * C;
-  tpo_joint_constraint_setup(p->q1, p->q2, N, D, p->vmax, p->amax, p->safety, A, B, lo_, hi_);
+  if (p->table_q) {
+    /* SamplePath :527-542: the segment of the IK table that starts at PathIkIndex(path_start) */
+    const int first = (int)round(p->path_start / p->delta);
+    const int last = (int)round(p->path_horizon / p->delta);
+    if (first < 0 || last - first != N - 1 || last >= p->table_len) { free(rows); return TPO_PLAN_INTERNAL; }
+    memcpy(p->q, p->table_q + (size_t)first * D, sizeof(double) * (size_t)N * D);
+    tpo_cartesian_path_derivatives(p->q, N, D, p->delta, p->q1, p->q2);
+    double *jq1 = (double *)malloc(sizeof(double) * 6 * (size_t)N);
+    tpo_cartesian_jacobian_times_q1(p->table_J + (size_t)first * 6 * D, p->q1, N, D, jq1);
+    tpo_cartesian_constraint_setup(p->q1, p->q2, jq1, N, D, p->vmax, p->amax, p->max_trans_vel,
+                                   p->max_rot_vel, p->safety, A, B, lo_, hi_);
+    free(jq1);
+  } else {
+    if (tpo_joint_sample_path(p->knots, p->num_knots, p->cps, p->num_points, D, p->path_start, p->delta,
+                              N, p->q, p->q1, p->q2) != 0) {
+      free(rows);
+      return TPO_PLAN_INTERNAL;
+    }
+    tpo_joint_constraint_setup(p->q1, p->q2, N, D, p->vmax, p->amax, p->safety, A, B, lo_, hi_);
+  }
+  p->path_state = TPO_PATH_SAMPLED;
   if (old_state == TPO_PATH_MODIFIED || old_state == TPO_PATH_NEW) {
     /* :360-393: least-squares start velocity along the start tangent; Eigen's squaredNorm and
      * dot are summed in index order here */
@@ -355,7 +403,7 @@ int tpo_planner_plan(tpo_planner *p, int64_t start, int64_t time_horizon) {
   const double start_sec = time_to_sec(start);
   const size_t D = (size_t)p->D;
   p->windows = 0;
-  if (p->knots == NULL) return TPO_PLAN_FAILED_PRECONDITION;
+  if (p->knots == NULL && p->table_q == NULL) return TPO_PLAN_FAILED_PRECONDITION;
   /* HandleTimeArguments :502-538 */
   if (p->initial_plan && start > p->end_time + seconds_to_duration(p->time_step_sec))
     return TPO_PLAN_OUT_OF_RANGE;

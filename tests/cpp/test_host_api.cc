@@ -11,6 +11,7 @@
 #include "../../x-edr-trajectory-planning_amd/host/batch_path_timing.h"
 #include "../../x-edr-trajectory-planning_amd/host/path_timing_trajectory.h"
 #include "../../x-edr-trajectory-planning_amd/host/time_optimal_path_timing.h"
+#include "../../x-edr-trajectory-planning_amd/host/timeable_path_cartesian_spline.h"
 #include "../../x-edr-trajectory-planning_amd/host/timeable_path_joint_spline.h"
 
 using namespace trajectory_planning;
@@ -607,6 +608,214 @@ static void TestPlanAgainstOracle() {
   }
 }
 
+// A TimeableCartesianSplinePath behind PathTimingTrajectory::SetPath (timeable_path_cartesian_spline.h:
+// 62-192), planned to its end by receding-horizon Plan calls, as the reference's Cartesian planner
+// tests do with test doubles for the kinematics (path_timing_trajectory_test.cc:548-937: 7 fake
+// joints = xyz + rotation vector + one null-space joint). The fake IK here is a pure function of the
+// targets, so the IK solution of a sample does not depend on when it was computed; the oracle's
+// planner is given the finished IK table and the Jacobian callback's values on it, replays the same
+// Plan calls, and every replanning step must agree bit for bit. Rotation-vector extraction and the
+// pose corner rounding restate Eigen / eigenmath algorithms: unpinned at the ulp level, but both
+// sides of this comparison see the same table.
+static void TestCartesianSplinePathPlanning() {
+  using Method = PathTimingTrajectoryOptions::TimeSamplingMethod;
+  using tpamd::compat::AngleAxisd;
+  using tpamd::compat::Matrix6Xd;
+  using tpamd::compat::Pose3d;
+  using tpamd::compat::Quaterniond;
+  using tpamd::compat::Vector3d;
+  const int64_t kMs = 1000000;
+  const int D = 7, N = 400;
+  auto fake_ik = [D](const VectorXd &, const std::vector<Pose3d> &poses, const std::vector<VectorXd> &joints,
+                     std::vector<VectorXd> *result) -> Status {
+    result->clear();
+    for (size_t i = 0; i < poses.size(); i++) {
+      VectorXd q(D);
+      for (int d = 0; d < 3; d++) q[d] = poses[i].translation()[d];
+      const AngleAxisd aa(poses[i].quaternion());
+      for (int d = 0; d < 3; d++) q[3 + d] = aa.axis[d] * aa.angle;
+      q[6] = joints[i][6];
+      result->push_back(q);
+    }
+    return tpamd::compat::OkStatus();
+  };
+  auto fake_jacobian = [D](const VectorXd &q, Matrix6Xd *J) -> Status {
+    for (int r = 0; r < 6; r++)
+      for (int d = 0; d < D; d++) (*J)(r, d) = 0.2 * std::sin(q[d] * (r + 1.0) + 0.31 * d) + (r == d ? 1.0 : 0.0);
+    return tpamd::compat::OkStatus();
+  };
+  auto make_pose = [](double x, double y, double z, double ax, double ay, double az, double angle) {
+    AngleAxisd aa;
+    const double n = std::sqrt(ax * ax + ay * ay + az * az);
+    aa.axis = Vector3d(ax / n, ay / n, az / n);
+    aa.angle = angle;
+    return Pose3d(aa.toQuaternion(), Vector3d(x, y, z));
+  };
+  for (Method method : {Method::kUniformlyInTime, Method::kSkipSamplesCloserThanTimeStep}) {
+    const std::vector<Pose3d> poses = {make_pose(0.3, 0.0, 0.4, 0, 0, 1, 0.1), make_pose(0.5, 0.25, 0.6, 0, 1, 0, 0.7),
+                                       make_pose(0.2, 0.5, 0.3, 1, 0, 0, 0.4), make_pose(0.45, 0.1, 0.5, 0, 0, 1, 1.0)};
+    std::vector<VectorXd> joints;
+    for (size_t i = 0; i < poses.size(); i++) {
+      VectorXd q(D);
+      for (int d = 0; d < 3; d++) q[d] = poses[i].translation()[d];
+      const AngleAxisd aa(poses[i].quaternion());
+      for (int d = 0; d < 3; d++) q[3 + d] = aa.axis[d] * aa.angle;
+      q[6] = 0.2 * (double)i - 0.3;
+      joints.push_back(q);
+    }
+    // delta so that the path needs several windows (the knot vector depends on the waypoints only)
+    CartesianPathOptions probe_opt;
+    probe_opt.set_num_dofs(D).set_num_path_samples(N);
+    probe_opt.set_path_ik_func(fake_ik).set_jacobian_func(fake_jacobian);
+    TimeableCartesianSplinePath probe(probe_opt);
+    CHECK(probe.SetWaypoints({poses.data(), poses.size()}, {joints.data(), joints.size()}).ok());
+    const double kend = probe.knots().back();
+    const double delta = 0.4 * kend / (N - 1);
+    CartesianPathOptions opt;
+    opt.set_num_dofs(D).set_num_path_samples(N).set_delta_parameter(delta);
+    opt.set_path_ik_func(fake_ik).set_jacobian_func(fake_jacobian);
+    auto path = std::make_shared<TimeableCartesianSplinePath>(opt);
+    PathTimingTrajectory planner(PathTimingTrajectoryOptions().SetTimeStep(Milliseconds(4)).SetNumDofs(D)
+                                     .SetNumPathSamples(N).SetTimeSamplingMethod(method));
+    CHECK(planner.SetPath(path).ok());
+    std::vector<double> vmax = {0.6, 0.5, 0.7, 1.0, 0.9, 1.1, 0.8}, amax = {1.5, 1.2, 1.8, 2.5, 2.0, 3.0, 2.2};
+    CHECK(path->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+    CHECK(path->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+    CHECK(path->SetMaxCartesianVelocity(0.35, 0.9).ok());
+    CHECK(!path->SetMaxCartesianVelocity(0.0, 1.0).ok());
+    CHECK(path->SetWaypoints({poses.data(), poses.size()}, {joints.data(), joints.size()}).ok());
+    CHECK(path->GetState() == TimeablePath::State::kNewPath);
+    CHECK(!path->SwitchToWaypointPath(0.1, {poses.data(), poses.size()}, {joints.data(), joints.size()}).ok());
+    CHECK(path->GetState() == TimeablePath::State::kNewPath);
+    // the mirror first, recording every step's trajectory
+    struct Step { int64_t start; std::vector<double> t, s; std::vector<double> pos, vel, acc; bool ok; };
+    std::vector<Step> steps;
+    int64_t start = 0;
+    while (!planner.IsTrajectoryAtEnd() && steps.size() < 100) {
+      Step st;
+      st.start = start;
+      st.ok = planner.Plan(tpamd::compat::FromUnixNanos(start), Milliseconds(750)).ok();
+      CHECK(st.ok);
+      if (!st.ok) break;
+      st.t.assign(planner.GetTime().begin(), planner.GetTime().end());
+      st.s.assign(planner.GetPathParameters().begin(), planner.GetPathParameters().end());
+      for (size_t i = 0; i < planner.GetPositions().size(); i++)
+        for (int d = 0; d < D; d++) {
+          st.pos.push_back(planner.GetPositions()[i][d]);
+          st.vel.push_back(planner.GetVelocities()[i][d]);
+          st.acc.push_back(planner.GetAccelerations()[i][d]);
+        }
+      steps.push_back(st);
+      const int64_t end_ns = tpamd::compat::ToUnixNanos(planner.GetEndTime());
+      start = std::min<int64_t>(end_ns, start + 200 * kMs);
+    }
+    CHECK(planner.IsTrajectoryAtEnd());
+    CHECK(steps.size() > 4);
+    // end of the motion: the last joint waypoint (through the fake IK), at rest
+    for (int d = 0; d < D; d++) {
+      CHECK(planner.GetVelocities().back()[d] == 0.0);
+      CHECK(std::fabs(planner.GetPositions().back()[d] - joints.back()[d]) < 1e-6);
+    }
+    // Cartesian speed limit along the trajectory (safety factor applies to joint limits only)
+    // the oracle on the finished IK table
+    const std::vector<VectorXd> &table = path->GetSplineIKPosition();
+    const int M = (int)table.size();
+    CHECK(M > N);
+    std::vector<double> tq((size_t)M * D), tJ((size_t)M * 6 * D);
+    Matrix6Xd J(6, D);
+    for (int i = 0; i < M; i++) {
+      for (int d = 0; d < D; d++) tq[(size_t)i * D + d] = table[i][d];
+      fake_jacobian(table[i], &J);
+      std::copy(J.data(), J.data() + 6 * D, tJ.begin() + (size_t)i * 6 * D);
+    }
+    tpo_planner *o = tpo_planner_create(D, N, delta, path->options().constraint_safety(), 4 * kMs,
+                                        method == Method::kUniformlyInTime ? 0 : 1, 10000, 1e-3);
+    tpo_planner_set_limits(o, vmax.data(), amax.data());
+    tpo_planner_set_ik_table(o, tq.data(), tJ.data(), M, path->knots().back(), 0.35, 0.9, TPO_PATH_NEW);
+    int windows = 0;
+    for (const Step &st : steps) {
+      const int rc = tpo_planner_plan(o, st.start, 750 * kMs);
+      CHECK(rc == TPO_PLAN_OK);
+      if (rc != TPO_PLAN_OK) break;
+      windows += tpo_planner_windows(o);
+      const int Mo = tpo_planner_num_samples(o);
+      CHECK(Mo == (int)st.t.size());
+      if (Mo != (int)st.t.size()) break;
+      for (int i = 0; i < Mo; i++) {
+        CHECK(st.t[i] == tpo_planner_time(o)[i]);
+        CHECK(st.s[i] == tpo_planner_path_parameter(o)[i]);
+      }
+      for (int i = 0; i < Mo * D; i++) {
+        CHECK(st.pos[i] == tpo_planner_positions(o)[i]);
+        CHECK(st.vel[i] == tpo_planner_velocities(o)[i]);
+        CHECK(st.acc[i] == tpo_planner_accelerations(o)[i]);
+      }
+    }
+    CHECK(windows >= 3);
+    CHECK(tpo_planner_target_reached(o) == 1);
+    tpo_planner_destroy(o);
+    // SamplePath / ConstraintSetup on their own give the rows the planner's fused call forms on
+    // the device: the two Cartesian rows have A = 0, lower = -upper (timeable_path_cartesian_spline.cc:578-592)
+    CHECK(path->SamplePath(0.0).ok());
+    CHECK(path->ConstraintSetup().ok());
+    const auto &rows = path->GetConstraints();
+    CHECK((int)rows.size() == N && rows[5].size() == 2 * D + 2);
+    CHECK(rows[5].a_coefficient(2 * D) == 0.0 && rows[5].lower(2 * D) == -rows[5].upper(2 * D));
+    CHECK(rows[5].upper(2 * D) == 0.35 * 0.35 && rows[5].upper(2 * D + 1) == 0.9 * 0.9);
+    CHECK(path->PathIkIndex(path->PathIkParameter(17)) == 17);
+  }
+  // several Cartesian planners of two shapes in one PlanBatch call equal one Plan each
+  {
+    std::vector<std::shared_ptr<TimeableCartesianSplinePath>> paths;
+    std::vector<std::unique_ptr<PathTimingTrajectory>> batch, single;
+    std::vector<PathTimingTrajectory *> ptrs;
+    for (int k = 0; k < 4; k++) {
+      const int Nk = (k % 2) ? 300 : 260;
+      for (int copy = 0; copy < 2; copy++) {
+        CartesianPathOptions opt;
+        opt.set_num_dofs(D).set_num_path_samples(Nk).set_delta_parameter(0.02 + 0.004 * k);
+        opt.set_path_ik_func(fake_ik).set_jacobian_func(fake_jacobian);
+        auto path = std::make_shared<TimeableCartesianSplinePath>(opt);
+        std::vector<double> vmax(D, 0.7 + 0.1 * k), amax(D, 1.5 + 0.2 * k);
+        CHECK(path->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+        CHECK(path->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+        CHECK(path->SetMaxCartesianVelocity(0.3 + 0.05 * k, 0.8).ok());
+        std::vector<Pose3d> poses = {make_pose(0.1 * k, 0.0, 0.4, 0, 0, 1, 0.1), make_pose(0.5, 0.2 + 0.05 * k, 0.6, 0, 1, 0, 0.5),
+                                     make_pose(0.2, 0.5, 0.3 + 0.02 * k, 1, 0, 0, 0.3)};
+        std::vector<VectorXd> joints;
+        for (size_t i = 0; i < poses.size(); i++) {
+          VectorXd q(D);
+          for (int d = 0; d < 3; d++) q[d] = poses[i].translation()[d];
+          const AngleAxisd aa(poses[i].quaternion());
+          for (int d = 0; d < 3; d++) q[3 + d] = aa.axis[d] * aa.angle;
+          q[6] = 0.1 * (double)i;
+          joints.push_back(q);
+        }
+        CHECK(path->SetWaypoints({poses.data(), poses.size()}, {joints.data(), joints.size()}).ok());
+        auto pl = std::make_unique<PathTimingTrajectory>(
+            PathTimingTrajectoryOptions().SetTimeStep(Milliseconds(4)).SetNumDofs(D).SetNumPathSamples(Nk));
+        CHECK(pl->SetPath(path).ok());
+        if (copy == 0) { ptrs.push_back(pl.get()); batch.push_back(std::move(pl)); }
+        else single.push_back(std::move(pl));
+      }
+    }
+    for (int round = 0; round < 3; round++) {
+      const auto start = tpamd::compat::FromUnixNanos((int64_t)round * 150 * kMs);
+      const auto st = PathTimingTrajectory::PlanBatch(ptrs, start, Milliseconds(500));
+      for (size_t k = 0; k < ptrs.size(); k++) {
+        CHECK(st[k].ok());
+        CHECK(single[k]->Plan(start, Milliseconds(500)).ok());
+        CHECK(batch[k]->GetTime() == single[k]->GetTime());
+        CHECK(batch[k]->GetPositions().size() == single[k]->GetPositions().size());
+        for (size_t i = 0; i < batch[k]->GetPositions().size(); i++) {
+          CHECK(batch[k]->GetPositions()[i] == single[k]->GetPositions()[i]);
+          CHECK(batch[k]->GetAccelerations()[i] == single[k]->GetAccelerations()[i]);
+        }
+      }
+    }
+  }
+}
+
 // SwitchToWaypointPath (timeable_path_joint_spline.cc:209-250) while a plan is being followed,
 // as in the reference's SwitchToNewJointWaypointPathWorks (path_timing_trajectory_test.cc:298-420):
 // plan, switch to a new waypoint path at a parameter ahead of the robot, carry the current
@@ -688,6 +897,7 @@ int main() {
   TestPlanBatch();
   TestPlanAgainstOracle();
   TestSwitchPathPlanning();
+  TestCartesianSplinePathPlanning();
   if (g_fail == 0) std::printf("ALL OK\n");
   else std::printf("%d CHECKS FAILED\n", g_fail);
   return g_fail == 0 ? 0 : 1;

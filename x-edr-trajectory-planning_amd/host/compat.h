@@ -50,6 +50,7 @@ inline Status InternalError(std::string m) { return Status(StatusCode::kInternal
 inline Status OutOfRangeError(std::string m) { return Status(StatusCode::kOutOfRange, std::move(m)); }
 inline Status UnimplementedError(std::string m) { return Status(StatusCode::kUnimplemented, std::move(m)); }
 inline Status DeadlineExceededError(std::string m) { return Status(StatusCode::kDeadlineExceeded, std::move(m)); }
+inline Status ResourceExhaustedError(std::string m) { return Status(StatusCode::kResourceExhausted, std::move(m)); }
 
 template <typename T>
 class StatusOr {
@@ -121,6 +122,116 @@ class ArrayXd {
   std::vector<double> v_;
 };
 using VectorXd = ArrayXd;
+
+// ---- poses ---------------------------------------------------------------------
+// What TimeableCartesianSplinePath needs from eigenmath::Pose3d / Eigen::Quaterniond /
+// Eigen::AngleAxisd / eigenmath::Matrix6Xd. eigenmath and Eigen are absent from this image; the
+// operations below restate Eigen 3.4's published scalar algorithms (quaternion product and
+// rotation of a vector, AngleAxis <-> quaternion), so results agree with an Eigen build to
+// rounding, not bit for bit (a vectorised Eigen sums in another order): parity at that level is
+// unpinned. They are used only in O(waypoints) host pre-processing.
+struct Vector3d {
+  double v[3] = {0.0, 0.0, 0.0};
+  Vector3d() = default;
+  Vector3d(double x, double y, double z) : v{x, y, z} {}
+  double &operator[](size_t i) { return v[i]; }
+  const double &operator[](size_t i) const { return v[i]; }
+  double norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+  Vector3d operator+(const Vector3d &o) const { return {v[0] + o.v[0], v[1] + o.v[1], v[2] + o.v[2]}; }
+  Vector3d operator-(const Vector3d &o) const { return {v[0] - o.v[0], v[1] - o.v[1], v[2] - o.v[2]}; }
+  Vector3d operator*(double s) const { return {v[0] * s, v[1] * s, v[2] * s}; }
+  Vector3d cross(const Vector3d &o) const {
+    return {v[1] * o.v[2] - v[2] * o.v[1], v[2] * o.v[0] - v[0] * o.v[2], v[0] * o.v[1] - v[1] * o.v[0]};
+  }
+};
+
+struct Quaterniond {
+  double w = 1.0, x = 0.0, y = 0.0, z = 0.0;
+  Quaterniond() = default;
+  Quaterniond(double w_, double x_, double y_, double z_) : w(w_), x(x_), y(y_), z(z_) {}
+  static Quaterniond Identity() { return Quaterniond(); }
+  Vector3d vec() const { return {x, y, z}; }
+  double squaredNorm() const { return w * w + x * x + y * y + z * z; }
+  Quaterniond normalized() const {
+    const double n = std::sqrt(squaredNorm());
+    return {w / n, x / n, y / n, z / n};
+  }
+  Quaterniond conjugate() const { return {w, -x, -y, -z}; }
+  Quaterniond inverse() const {           // Eigen: conjugate / squaredNorm (zero stays zero)
+    const double n2 = squaredNorm();
+    if (!(n2 > 0.0)) return {0.0, 0.0, 0.0, 0.0};
+    return {w / n2, -x / n2, -y / n2, -z / n2};
+  }
+  Quaterniond operator*(const Quaterniond &b) const {   // Hamilton product
+    return {w * b.w - x * b.x - y * b.y - z * b.z, w * b.x + x * b.w + y * b.z - z * b.y,
+            w * b.y + y * b.w + z * b.x - x * b.z, w * b.z + z * b.w + x * b.y - y * b.x};
+  }
+  Vector3d operator*(const Vector3d &p) const {         // Eigen _transformVector
+    const Vector3d u = vec();
+    const Vector3d uv = u.cross(p) * 2.0;
+    return p + uv * w + u.cross(uv);
+  }
+};
+
+// Eigen::AngleAxisd(Quaterniond) and back (Eigen/src/Geometry/AngleAxis.h)
+struct AngleAxisd {
+  double angle = 0.0;
+  Vector3d axis{1.0, 0.0, 0.0};
+  AngleAxisd() = default;
+  explicit AngleAxisd(const Quaterniond &q) {
+    double n = q.vec().norm();
+    if (n != 0.0) {
+      angle = 2.0 * std::atan2(n, std::fabs(q.w));
+      if (q.w < 0) n = -n;
+      axis = Vector3d(q.x / n, q.y / n, q.z / n);
+    }
+  }
+  Quaterniond toQuaternion() const {
+    const double ha = 0.5 * angle;
+    const double s = std::sin(ha);
+    return {std::cos(ha), s * axis[0], s * axis[1], s * axis[2]};
+  }
+};
+
+// eigenmath::Pose3d: a unit quaternion and a translation; a * b composes, inverse() inverts.
+class Pose3d {
+ public:
+  Pose3d() = default;
+  Pose3d(const Quaterniond &q, const Vector3d &t) : q_(q), t_(t) {}
+  const Quaterniond &quaternion() const { return q_; }
+  void setQuaternion(const Quaterniond &q) { q_ = q; }
+  Vector3d &translation() { return t_; }
+  const Vector3d &translation() const { return t_; }
+  Pose3d inverse() const {
+    const Quaterniond qi = q_.inverse();
+    return Pose3d(qi, (qi * t_) * -1.0);
+  }
+  Pose3d operator*(const Pose3d &b) const { return Pose3d(q_ * b.q_, t_ + q_ * b.t_); }
+
+ private:
+  Quaterniond q_;
+  Vector3d t_;
+};
+
+// eigenmath::Matrix6Xd as the Jacobian callback fills it: 6 x cols, (row, col) access; stored
+// row-major, which is what the engine's Cartesian entry points take ([6][D] per sample).
+class Matrix6Xd {
+ public:
+  Matrix6Xd() = default;
+  Matrix6Xd(size_t rows, size_t cols) : cols_(cols), v_(6 * cols, 0.0) { (void)rows; }
+  void resize(size_t rows, size_t cols) { (void)rows; cols_ = cols; v_.assign(6 * cols, 0.0); }
+  void setZero() { for (auto &x : v_) x = 0.0; }
+  size_t rows() const { return 6; }
+  size_t cols() const { return cols_; }
+  double &operator()(size_t r, size_t c) { return v_[r * cols_ + c]; }
+  const double &operator()(size_t r, size_t c) const { return v_[r * cols_ + c]; }
+  const double *data() const { return v_.data(); }
+  double *data() { return v_.data(); }
+
+ private:
+  size_t cols_ = 0;
+  std::vector<double> v_;
+};
 
 // ---- time ------------------------------------------------------------------------
 // Nanosecond-resolution time point / duration with the handful of operations

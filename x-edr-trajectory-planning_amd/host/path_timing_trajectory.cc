@@ -7,6 +7,7 @@
 #include <tuple>
 
 #include "engine_handle.h"
+#include "timeable_path_cartesian_spline.h"
 #include "timeable_path_joint_spline.h"
 
 namespace trajectory_planning {
@@ -177,7 +178,7 @@ Status PathTimingTrajectory::ProjectStartVelocity(const Window &w) {
 void PathTimingTrajectory::PlanJointWindowsOnDevice(const std::vector<PathTimingTrajectory *> &planners,
                                                     const std::vector<size_t> &ids, Time start,
                                                     Duration time_horizon, std::vector<Status> *status) {
-  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine(planners[ids[0]]->device_);
   tpamd_engine *engine = lease.get();
   if (!engine) {
     for (size_t id : ids) (*status)[id] = InternalError("no GPU engine");
@@ -345,6 +346,9 @@ void PathTimingTrajectory::PlanJointWindowsOnDevice(const std::vector<PathTiming
         break;
       case TPAMD_PLAN_DEADLINE_EXCEEDED:
         (*status)[ids[g]] = DeadlineExceededError("Reached maximum number of planning loops"); break;
+      case TPAMD_PLAN_MORE:   // (64 doublings of the history buffer were not enough: not a solver failure)
+        (*status)[ids[g]] = ::tpamd::compat::ResourceExhaustedError(
+            "window history still growing after 64 extensions of its buffer"); break;
       default: (*status)[ids[g]] = InternalError("Error optimizing path parameter"); break;
     }
   }
@@ -379,6 +383,73 @@ Status PathTimingTrajectory::SolveWindowOnHost(Window *w) {
   }
   w->status = 0;
   return OkStatus();
+}
+
+// One window each for planners whose path is a TimeableCartesianSplinePath: the path samples its
+// pose splines on the GPU and runs the user's path-IK callback (SamplePath), the Jacobian callback
+// is evaluated at every sample, and then everything that follows in ComputeTimingProfile --
+// path derivatives, the 2D + 2 constraint rows, the solver, the epilogue -- is ONE engine call per
+// group of equal (dofs, samples, safety): tpamd_time_cartesian_paths_host.
+void PathTimingTrajectory::SolveCartesianWindows(const std::vector<PathTimingTrajectory *> &planners,
+                                                 const std::vector<size_t> &ids, std::vector<Window> *windows,
+                                                 std::vector<Status> *status) {
+  std::map<std::tuple<int, size_t, size_t, double>, std::vector<size_t>> groups;
+  for (size_t i : ids) {
+    PathTimingTrajectory *pl = planners[i];
+    auto *path = dynamic_cast<TimeableCartesianSplinePath *>(pl->path_.get());
+    Status st = path->SamplePath(pl->path_start_);
+    if (st.ok()) st = pl->ProjectStartVelocity((*windows)[i]);
+    (*status)[i] = st;
+    if (st.ok())
+      groups[std::make_tuple(pl->device_, path->NumDofs(), path->NumPathSamples(),
+                             path->options().constraint_safety())].push_back(i);
+  }
+  for (const auto &kv : groups) {
+    const std::vector<size_t> &g = kv.second;
+    const size_t B = g.size(), D = std::get<1>(kv.first), N = std::get<2>(kv.first);
+    std::vector<double> q, J, vmax(B * D), amax(B * D), vt(B), vr(B), ps(B), dl(B), sd0(B), sdd0(B), t0(B);
+    q.reserve(B * N * D); J.reserve(B * N * 6 * D);
+    bool packed = true;
+    for (size_t k = 0; k < B && packed; k++) {
+      PathTimingTrajectory *pl = planners[g[k]];
+      auto *path = dynamic_cast<TimeableCartesianSplinePath *>(pl->path_.get());
+      const Status st = path->PackSampledWindow(&q, &J);      // the user's Jacobian callback, once per sample
+      if (!st.ok()) { for (size_t i : g) (*status)[i] = st; packed = false; break; }
+      for (size_t d = 0; d < D; d++) {
+        vmax[k * D + d] = path->GetMaxJointVelocity()[d];
+        amax[k * D + d] = path->GetMaxJointAcceleration()[d];
+      }
+      vt[k] = path->max_translational_velocity(); vr[k] = path->max_rotational_velocity();
+      ps[k] = pl->path_start_; dl[k] = path->GetPathSamplingDistance();
+      sd0[k] = pl->path_start_velocity_; sdd0[k] = pl->path_start_acceleration_; t0[k] = pl->path_time_start_;
+    }
+    if (!packed) continue;
+    std::vector<double> t(B * N), s(B * N), sd(B * N), sdd(B * N), sd2(B * N), qd(B * N * D), qdd(B * N * D), dtm(B);
+    std::vector<int32_t> st(B, -1), lei(B, 0);
+    tpamd_cartesian_batch batch{(int)B, (int)D, (int)N, 0, std::get<3>(kv.first)};
+    tpamd_cartesian_inputs in{q.data(), J.data(), vmax.data(), amax.data(), vt.data(), vr.data(), ps.data(),
+                              dl.data(), sd0.data(), sdd0.data(), t0.data()};
+    tpamd_path_outputs out{t.data(), s.data(), sd.data(), sdd.data(), nullptr, qd.data(), qdd.data(), lei.data(),
+                           dtm.data(), st.data(), sd2.data()};
+    int rc;
+    {
+      ::tpamd::EngineLease lease = ::tpamd::acquire_engine(planners[g[0]]->device_);
+      rc = lease ? tpamd_time_cartesian_paths_host(lease.get(), &batch, &in, &out) : TPAMD_E_NO_DEVICE;
+    }
+    for (size_t k = 0; k < B; k++) {
+      const size_t i = g[k];
+      PathTimingTrajectory *pl = planners[i];
+      if (rc != 0) { (*status)[i] = InternalError(tpamd_error_string(rc)); continue; }
+      if (st[k] != 0) { (*status)[i] = InternalError("Error optimizing path parameter"); continue; }
+      pl->profile_.AdoptSolution((int)N, (int)(2 * D + 2), pl->path_start_, pl->path_horizon_, &t[k * N], &s[k * N],
+                                 &sd[k * N], &sdd[k * N], &sd2[k * N], lei[k], dtm[k]);
+      Window &w = (*windows)[i];
+      std::copy_n(q.begin() + k * N * D, N * D, w.q.begin());
+      std::copy_n(qd.begin() + k * N * D, N * D, w.qd.begin());
+      std::copy_n(qdd.begin() + k * N * D, N * D, w.qdd.begin());
+      w.status = 0;
+    }
+  }
 }
 
 // Phase 3: drop what the new window replaces, then append it (path_timing_trajectory.cc:418-456).
@@ -539,12 +610,16 @@ std::vector<Status> PathTimingTrajectory::PlanBatch(const std::vector<PathTiming
   // TimeableJointSplinePath planners: all windows of this call chained on the device, one engine
   // call per shape group. Other TimeablePath types: the window loop on the host below.
   {
-    std::map<std::tuple<size_t, size_t, size_t, double>, std::vector<size_t>> groups;
+    std::map<std::tuple<int, size_t, size_t, size_t, double, int, double>, std::vector<size_t>> groups;
     for (size_t i = 0; i < P; i++) {
       if (!finish[i]) continue;
       if (auto *joint = dynamic_cast<TimeableJointSplinePath *>(planners[i]->path_.get())) {
-        groups[std::make_tuple(joint->NumDofs(), joint->NumPathSamples(), (size_t)joint->num_control_points(),
-                               joint->options().constraint_safety())].push_back(i);
+        // (planners whose options differ in the loop limit or the start-velocity tolerance are
+        // solved by separate engine calls: one value of each per call)
+        groups[std::make_tuple(planners[i]->device_, joint->NumDofs(), joint->NumPathSamples(),
+                               (size_t)joint->num_control_points(), joint->options().constraint_safety(),
+                               planners[i]->options_.GetMaxPlanningIterations(),
+                               planners[i]->options_.GetMaxInitialVelocityError())].push_back(i);
         looping[i] = 0;            // handled here, not by the host loop
       }
     }
@@ -555,7 +630,7 @@ std::vector<Status> PathTimingTrajectory::PlanBatch(const std::vector<PathTiming
     }
   }
   for (;;) {
-    std::vector<size_t> foreign;
+    std::vector<size_t> foreign, cartesian;
     bool any = false;
     for (size_t i = 0; i < P; i++) {
       if (!looping[i]) continue;
@@ -563,10 +638,12 @@ std::vector<Status> PathTimingTrajectory::PlanBatch(const std::vector<PathTiming
       PathTimingTrajectory *pl = planners[i];
       status[i] = pl->BeginWindow(loop_start[i], start + time_horizon - loop_start[i], &windows[i]);
       if (!status[i].ok()) { looping[i] = 0; finish[i] = 0; continue; }
-      foreign.push_back(i);
+      if (dynamic_cast<TimeableCartesianSplinePath *>(pl->path_.get())) cartesian.push_back(i);
+      else foreign.push_back(i);
     }
     if (!any) break;
     for (size_t i : foreign) status[i] = planners[i]->SolveWindowOnHost(&windows[i]);
+    if (!cartesian.empty()) SolveCartesianWindows(planners, cartesian, &windows, &status);
     // phase 3 and the loop bookkeeping of path_timing_trajectory.cc:640-660
     for (size_t i = 0; i < P; i++) {
       if (!looping[i]) continue;
@@ -613,7 +690,7 @@ Status PathTimingTrajectory::ResampleEquidistantlyInTime(double start_sec) {
   const double duration = time_at_path_samples_.back() - start_sec;
   const int M = (int)(std::ceil(duration / time_step_sec_) + 1);
   if (M < 1) return InternalError("negative trajectory duration");
-  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine(device_);
   tpamd_engine *engine = lease.get();
   if (!engine) return InternalError("no GPU engine");
   std::vector<double> ot(M), os(M), osd(M), osdd(M), oq((size_t)M * D), oqd((size_t)M * D), oqdd((size_t)M * D);
@@ -652,7 +729,7 @@ void PathTimingTrajectory::ResampleSkippingSamplesCloserThanTimeStep(double star
   const int S = (int)time_at_path_samples_.size();
   time_.clear(); positions_.clear(); velocities_.clear(); accelerations_.clear();
   path_parameter_.clear(); path_parameter_derivative_.clear(); second_path_parameter_derivative_.clear();
-  ::tpamd::EngineLease lease = ::tpamd::acquire_engine();
+  ::tpamd::EngineLease lease = ::tpamd::acquire_engine(device_);
   tpamd_engine *engine = lease.get();
   if (!engine || S < 2) return;
   const int cap = S + 1;

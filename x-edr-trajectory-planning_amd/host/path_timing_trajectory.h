@@ -46,6 +46,10 @@ class PathTimingTrajectory : public TrajectoryPlanner {
   // Plan(start, time_horizon) would have left it in; the result holds one status per planner.
   static std::vector<Status> PlanBatch(const std::vector<PathTimingTrajectory *> &planners, Time start,
                                        Duration time_horizon);
+  // The HIP device this planner's engine calls run on (default: TPAMD_DEVICE, else 0). PlanBatch
+  // groups planners by device as well, so planners of different devices are solved side by side.
+  void SetDevice(int device) { device_ = device; }
+  int GetDevice() const { return device_; }
   size_t NumTimeSamples() const { return time_.size(); }
   Time GetFinalDecelStart() const { return final_decel_start_; }
   Time GetNextPlanStartTime(Time target_time);
@@ -73,6 +77,9 @@ class PathTimingTrajectory : public TrajectoryPlanner {
   Status BeginWindow(Time start, Duration target_duration, Window *w);   // up to the path sampling
   Status ProjectStartVelocity(const Window &w);                          // after sampling, :360-377
   Status SolveWindowOnHost(Window *w);                                   // foreign TimeablePath types
+  static void SolveCartesianWindows(const std::vector<PathTimingTrajectory *> &planners,
+                                    const std::vector<size_t> &ids, std::vector<Window> *windows,
+                                    std::vector<Status> *status);       // TimeableCartesianSplinePath
   Status EndWindow(Window *w);                                           // adopt + append, :418-456
   // Plan() split around its window loop
   Status PlanPrologue(Time start, Duration time_horizon, bool *needs_windows);
@@ -99,6 +106,7 @@ class PathTimingTrajectory : public TrajectoryPlanner {
 
   const PathTimingTrajectoryOptions options_;
   const double time_step_sec_;
+  int device_ = -1;   // HIP device this planner's engine calls use (-1: the default device)
   Time final_decel_start_;
   double path_horizon_ = 0, path_time_start_ = 0, path_start_ = 0, path_start_velocity_ = 0,
          path_start_acceleration_ = 0;

@@ -64,11 +64,13 @@ class TimeableJointSplinePath : public TimeablePath {
   int num_control_points() const { return (int)control_points_.size(); }
   // Installs samples computed by a fused engine call (planner / batch front ends).
   void AdoptSamples(double path_start, const double *q, const double *q1, const double *q2);
+  // splines/spline_utils.cc:47-102 (PolyLineToBspline3Waypoints, vector variant): W corners ->
+  // 3W - 2 control points with rounded corners. Also used by the Cartesian path's joint spline.
+  static void PolyLineToControlPoints(const std::vector<VectorXd> &waypoints, double radius,
+                                      std::vector<VectorXd> *control_points);
 
  private:
   Status FitSplineToWaypoints();
-  static void PolyLineToControlPoints(const std::vector<VectorXd> &waypoints, double radius,
-                                      std::vector<VectorXd> *control_points);
   void PackControlPoints();
 
   static constexpr int kSplineOrder = 2;
