@@ -327,6 +327,76 @@ typedef struct tpamd_plan_args {
 
 int tpamd_plan_joint_windows_host(tpamd_engine *engine, const tpamd_plan_args *args);
 
+/* ------------------------------------------------------------------------
+ * Planner sets: B PathTimingTrajectory planners (path_timing_trajectory.h:91-186) with
+ * TimeableJointSplinePath paths of one shape whose WHOLE state lives on the device between Plan
+ * calls -- the spline and limits, the window history (*_at_path_samples_), the planner scalars
+ * (path_horizon_, planned_to_end_, final_decel_start_, start/end time, initial_plan_ ...), the
+ * profile of the last window, and the resampled trajectory (time_, positions_, ...).
+ * tpamd_planner_set_plan is Plan(start, time_horizon) (path_timing_trajectory.cc:579-684) for all
+ * of them at once, entirely on the device: HandleTimeArguments :502-538, UpdatePathTrackingStatus
+ * :477-500, the "planned enough" branch with EraseTrajectoryBefore :540-577 (both sampling
+ * methods), the truncation at GetTimeOffsetAfter :604-621, the window loop :628-660 chained as in
+ * tpamd_plan_joint_windows_host, ResampleTrajectory :755-836 and the bookkeeping of :662-684.
+ * A Plan call moves 16 bytes per planner up (the two time arguments) and one status + summary
+ * record down, plus a few words per window iteration; trajectories come down only when asked for
+ * (tpamd_planner_set_download_trajectory). The mirror's PathTimingTrajectorySet wraps this.
+ * History and trajectory buffers grow on the device when a planner needs more room.
+ * ------------------------------------------------------------------------ */
+typedef struct tpamd_planner_set tpamd_planner_set;
+
+typedef struct tpamd_planner_set_config {
+  int32_t num_planners, num_dofs, num_samples, num_points;
+  int32_t history_capacity;        /* samples per planner to start with; <= 0: 8 * num_samples */
+  int32_t trajectory_capacity;     /* resampled samples per planner to start with; <= 0: 4096 */
+  int32_t sampling_method;         /* 0 kUniformlyInTime, 1 kSkipSamplesCloserThanTimeStep */
+  int32_t max_planning_iterations; /* PathTimingTrajectoryOptions::GetMaxPlanningIterations */
+  double constraint_safety;        /* PathOptions::constraint_safety */
+  double max_initial_velocity_error;
+  int64_t time_step_ns;            /* TrajectoryPlannerOptions::GetTimeStep */
+} tpamd_planner_set_config;
+
+typedef struct tpamd_planner_summary {
+  int64_t end_time_ns, final_decel_start_ns, start_time_ns; /* GetEndTime, GetFinalDecelStart, GetStartTime */
+  int32_t num_samples;     /* GetNumTimeSamples */
+  int32_t target_reached;  /* with path_state: IsTrajectoryAtEnd */
+  int32_t planned_to_end;
+  int32_t windows;         /* timing windows solved by this Plan call */
+  int32_t path_state;      /* TimeablePath::State after the call (3 = kPathWasSampled) */
+  int32_t history_count;   /* size of time_at_path_samples_ */
+  int32_t status;          /* TPAMD_PLAN_* */
+  int32_t reserved;
+} tpamd_planner_summary;
+
+int tpamd_planner_set_create(tpamd_engine *engine, const tpamd_planner_set_config *config,
+                             tpamd_planner_set **out);
+void tpamd_planner_set_destroy(tpamd_planner_set *set);
+/* The paths of `count` planners (ids[count], or planners 0..count-1 if ids is NULL) after
+ * SetWaypoints (path_state 1 = kNewPath) or SwitchToWaypointPath (2 = kModifiedPath), which stay on
+ * the host (O(waypoints) spline edits): knots [count][P+3], control_points [count][P][D],
+ * max_velocity / max_acceleration / initial_velocity [count][D], delta [count]. Host pointers. */
+int tpamd_planner_set_upload_paths(tpamd_planner_set *set, int count, const int32_t *ids,
+                                   const double *knots, const double *control_points,
+                                   const double *max_velocity, const double *max_acceleration,
+                                   const double *delta, const double *initial_velocity,
+                                   const int32_t *path_state);
+/* TrajectoryPlanner::Reset for the listed planners (ids NULL: all): no path, no plan. */
+int tpamd_planner_set_reset(tpamd_planner_set *set, int count, const int32_t *ids);
+/* Plan(start, time_horizon) for every planner: start_ns / horizon_ns [B] host arrays;
+ * summary [B] (host, may be NULL) receives one record per planner, status included. */
+int tpamd_planner_set_plan(tpamd_planner_set *set, const int64_t *start_ns, const int64_t *horizon_ns,
+                           tpamd_planner_summary *summary);
+/* The trajectory of one planner after its last Plan: samples first .. first + count - 1 of
+ * GetTime / GetPathParameters / ...Derivatives [count] and GetPositions / GetVelocities /
+ * GetAccelerations [count][D] into host arrays (any may be NULL). */
+int tpamd_planner_set_download_trajectory(tpamd_planner_set *set, int planner, int first, int count,
+                                          double *time, double *s, double *sd, double *sdd,
+                                          double *q, double *qd, double *qdd);
+/* Bytes the last tpamd_planner_set_plan call moved over PCIe (host to device, device to host). */
+void tpamd_planner_set_last_plan_bytes(const tpamd_planner_set *set, size_t *host_to_device,
+                                       size_t *device_to_host);
+size_t tpamd_planner_set_device_bytes(const tpamd_planner_set *set);
+
 /* Batched TimeOptimalPathProfile::FindMaxSd2Simplex (time_optimal_path_timing.cc:1149-1363)
  * on num_lps independent constraint sets of C rows each ([num_lps][C] arrays);
  * outputs sd2max/sddmax/sd2zero [num_lps]. Host pointers. */

@@ -10,6 +10,7 @@
 #include "../../x-edr-trajectory-planning_amd/host/batch_cartesian_timing.h"
 #include "../../x-edr-trajectory-planning_amd/host/batch_path_timing.h"
 #include "../../x-edr-trajectory-planning_amd/host/path_timing_trajectory.h"
+#include "../../x-edr-trajectory-planning_amd/host/path_timing_trajectory_set.h"
 #include "../../x-edr-trajectory-planning_amd/host/time_optimal_path_timing.h"
 #include "../../x-edr-trajectory-planning_amd/host/timeable_path_cartesian_spline.h"
 #include "../../x-edr-trajectory-planning_amd/host/timeable_path_joint_spline.h"
@@ -816,6 +817,165 @@ static void TestCartesianSplinePathPlanning() {
   }
 }
 
+// PathTimingTrajectorySet: planners whose state lives on the device (tpamd_planner_set_*). Every
+// planner must equal the oracle's Plan bit for bit at every replanning step -- window loop,
+// resampling in time (both methods), the "planned enough" erase branch, a new path after the end
+// of the old one, error statuses -- while a Plan call moves only a few bytes per planner.
+static void TestPlannerSet() {
+  using Method = PathTimingTrajectoryOptions::TimeSamplingMethod;
+  const int64_t kMs = 1000000;
+  const int K = 6, D = 7, N = 400, W = 5, P = 3 * W - 2;
+  for (Method method : {Method::kUniformlyInTime, Method::kSkipSamplesCloserThanTimeStep}) {
+    const bool skip = method == Method::kSkipSamplesCloserThanTimeStep;
+    const int64_t step_ns = skip ? 4 * kMs : 1 * kMs;      // 1 ms: the long path outgrows 4096 trajectory samples
+    unsigned long long seed = skip ? 9001 : 31337;
+    auto rnd = [&]() { seed = seed * 6364136223846793005ULL + 1442695040888963407ULL; return (double)(seed >> 11) / 9007199254740992.0; };
+    PathTimingTrajectoryOptions opt;
+    opt.SetNumDofs(D).SetNumPathSamples(N).SetTimeStep(tpamd::compat::Nanoseconds(step_ns)).SetTimeSamplingMethod(method);
+    PathTimingTrajectorySet set(opt, K + 1, P);             // the last planner never gets a path
+    CHECK(set.status().ok());
+    if (!set.status().ok()) return;
+    std::vector<std::shared_ptr<TimeableJointSplinePath>> paths(K);
+    std::vector<tpo_planner *> oracles(K);
+    auto make_path = [&](int k, double fraction) {
+      std::vector<VectorXd> wps;
+      for (int i = 0; i < W; i++) { VectorXd v(D); for (int d = 0; d < D; d++) v[d] = 5.0 * rnd() - 2.5; wps.push_back(v); }
+      auto probe = std::make_shared<TimeableJointSplinePath>(JointPathOptions().set_num_dofs(D).set_num_path_samples(N));
+      probe->SetWaypoints({wps.data(), wps.size()});
+      const double delta = fraction * probe->knots().back() / (N - 1);
+      auto path = std::make_shared<TimeableJointSplinePath>(
+          JointPathOptions().set_num_dofs(D).set_num_path_samples(N).set_delta_parameter(delta));
+      std::vector<double> vmax(D), amax(D);
+      for (int d = 0; d < D; d++) { vmax[d] = 1.0 + rnd(); amax[d] = 2.0 + 2.0 * rnd(); }
+      CHECK(path->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+      CHECK(path->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+      CHECK(path->SetWaypoints({wps.data(), wps.size()}).ok());
+      (void)k;
+      return path;
+    };
+    auto oracle_set_path = [&](tpo_planner *o, const TimeableJointSplinePath &p, int state) {
+      tpo_planner_set_limits(o, p.GetMaxJointVelocity().data(), p.GetMaxJointAcceleration().data());
+      tpo_planner_set_spline(o, p.knots().data(), (int)p.knots().size(), p.packed_control_points().data(),
+                             p.num_control_points(), state);
+    };
+    for (int k = 0; k < K; k++) {
+      // the last one needs ~25 windows in a single call: its history outgrows the initial 8 N samples
+      paths[k] = make_path(k, k == K - 1 ? 0.05 : 0.3 + 0.05 * k);
+      oracles[k] = tpo_planner_create(D, N, paths[k]->GetPathSamplingDistance(), 0.8, step_ns, skip ? 1 : 0, 200, 1e-2);
+      oracle_set_path(oracles[k], *paths[k], TPO_PATH_NEW);
+    }
+    CHECK(set.SetPaths(paths).ok());
+    auto compare = [&](int k) {
+      tpo_planner *o = oracles[k];
+      const int M = tpo_planner_num_samples(o);
+      CHECK((int)set.GetNumTimeSamples(k) == M);
+      CHECK(tpamd::compat::ToUnixNanos(set.GetEndTime(k)) == tpo_planner_end_time(o));
+      CHECK(tpamd::compat::ToUnixNanos(set.GetFinalDecelStart(k)) == tpo_planner_final_decel_start(o));
+      CHECK(set.IsTrajectoryAtEnd(k) == (tpo_planner_target_reached(o) != 0 && tpo_planner_path_state(o) == TPO_PATH_SAMPLED));
+      CHECK(set.WindowsOfLastPlan(k) == tpo_planner_windows(o));
+      PlannedTrajectory tr;
+      CHECK(set.GetTrajectory(k, &tr).ok());
+      if ((int)tr.time.size() != M) return;
+      for (int i = 0; i < M; i++) {
+        CHECK(tr.time[i] == tpo_planner_time(o)[i]);
+        CHECK(tr.path_parameter[i] == tpo_planner_path_parameter(o)[i]);
+        CHECK(tr.path_parameter_derivative[i] == tpo_planner_path_velocity(o)[i]);
+        CHECK(tr.second_path_parameter_derivative[i] == tpo_planner_path_acceleration(o)[i]);
+      }
+      for (int i = 0; i < M * D; i++) {
+        CHECK(tr.positions[i] == tpo_planner_positions(o)[i]);
+        CHECK(tr.velocities[i] == tpo_planner_velocities(o)[i]);
+        CHECK(tr.accelerations[i] == tpo_planner_accelerations(o)[i]);
+      }
+    };
+    auto code_of = [](const Status &st) {
+      using tpamd::compat::StatusCode;
+      switch (st.code()) {
+        case StatusCode::kOk: return (int)TPO_PLAN_OK;
+        case StatusCode::kFailedPrecondition: return (int)TPO_PLAN_FAILED_PRECONDITION;
+        case StatusCode::kOutOfRange: return (int)TPO_PLAN_OUT_OF_RANGE;
+        case StatusCode::kInvalidArgument: return (int)TPO_PLAN_INVALID_ARGUMENT;
+        case StatusCode::kDeadlineExceeded: return (int)TPO_PLAN_DEADLINE_EXCEEDED;
+        default: return (int)TPO_PLAN_INTERNAL;
+      }
+    };
+    int64_t start = 3 * 1000 * kMs;
+    size_t max_bytes = 0;
+    for (int round = 0; round < 7; round++) {
+      const int64_t horizon = round == 4 ? (int64_t)1000 * 1000 * kMs : 600 * kMs;
+      const auto st = set.Plan(tpamd::compat::FromUnixNanos(start), tpamd::compat::Nanoseconds(horizon));
+      max_bytes = std::max(max_bytes, set.LastPlanBytesOverPcie());
+      CHECK(st[K].code() == tpamd::compat::StatusCode::kFailedPrecondition);    // no path set
+      for (int k = 0; k < K; k++) {
+        const int rc = tpo_planner_plan(oracles[k], start, horizon);
+        CHECK(code_of(st[k]) == rc);
+        if (rc == TPO_PLAN_OK) compare(k);
+      }
+      // rounds 5, 6: everything is planned to the end -- only the erase branch runs
+      if (round >= 5) for (int k = 0; k < K; k++) CHECK(set.WindowsOfLastPlan(k) == 0);
+      start += round >= 4 ? 137 * kMs + 12345 : 150 * kMs;
+    }
+    for (int k = 0; k < K; k++) CHECK(set.IsTrajectoryAtEnd(k));
+    // a Plan call moves a few bytes per planner, not the histories
+    CHECK(max_bytes < (size_t)(K + 1) * 100 + 4096);
+    // error statuses: a start beyond the previous plan's end, and one before its start
+    {
+      std::vector<tpamd::compat::Time> starts(K + 1, tpamd::compat::FromUnixNanos(start));
+      std::vector<tpamd::compat::Duration> hor(K + 1, Milliseconds(600));
+      starts[0] = tpamd::compat::FromUnixNanos(tpo_planner_end_time(oracles[0]) + 50 * kMs);
+      starts[1] = tpamd::compat::FromUnixNanos(1000 * kMs);
+      const auto st = set.Plan(starts, hor);
+      for (int k = 0; k < K; k++) {
+        const int rc = tpo_planner_plan(oracles[k], tpamd::compat::ToUnixNanos(starts[k]), 600 * kMs);
+        CHECK(code_of(st[k]) == rc);
+        if (rc == TPO_PLAN_OK) compare(k);
+      }
+      CHECK(!st[0].ok() && !st[1].ok());
+    }
+    // New paths after the old ones were finished. Planner 2 keeps its planner state (the reference's
+    // use: SetWaypoints on the path object the planner holds; UpdatePathTrackingStatus then resets
+    // the path bookkeeping, :488-497) -- same sampling distance as before, which the oracle object
+    // fixes at creation. Planner 4 is Reset first and gets a path with another sampling distance.
+    {
+      const double delta2 = paths[2]->GetPathSamplingDistance();
+      std::vector<VectorXd> wps;
+      for (int i = 0; i < W; i++) { VectorXd v(D); for (int d = 0; d < D; d++) v[d] = 4.0 * rnd() - 2.0; wps.push_back(v); }
+      auto path = std::make_shared<TimeableJointSplinePath>(
+          JointPathOptions().set_num_dofs(D).set_num_path_samples(N).set_delta_parameter(delta2));
+      std::vector<double> vmax(D, 1.3), amax(D, 2.6);
+      CHECK(path->SetMaxJointVelocity({vmax.data(), vmax.size()}).ok());
+      CHECK(path->SetMaxJointAcceleration({amax.data(), amax.size()}).ok());
+      CHECK(path->SetWaypoints({wps.data(), wps.size()}).ok());
+      paths[2] = path;
+      CHECK(set.SetPath(2, *paths[2]).ok());
+      oracle_set_path(oracles[2], *paths[2], TPO_PATH_NEW);
+      paths[4] = make_path(4, 0.4);
+      set.Reset(4);
+      CHECK(set.SetPath(4, *paths[4]).ok());
+      tpo_planner_destroy(oracles[4]);
+      oracles[4] = tpo_planner_create(D, N, paths[4]->GetPathSamplingDistance(), 0.8, step_ns, skip ? 1 : 0, 200, 1e-2);
+      oracle_set_path(oracles[4], *paths[4], TPO_PATH_NEW);
+    }
+    start += 500 * kMs;
+    for (int round = 0; round < 3; round++) {
+      const int64_t horizon = round == 2 ? (int64_t)1000 * 1000 * kMs : 700 * kMs;
+      std::vector<tpamd::compat::Time> starts(K + 1, tpamd::compat::FromUnixNanos(start));
+      std::vector<tpamd::compat::Duration> hor(K + 1, tpamd::compat::Nanoseconds(horizon));
+      const auto st = set.Plan(starts, hor);
+      for (int k : {2, 4}) {
+        const int rc = tpo_planner_plan(oracles[k], start, horizon);
+        CHECK(code_of(st[k]) == rc && rc == TPO_PLAN_OK);
+        if (rc == TPO_PLAN_OK) compare(k);
+      }
+      start += 180 * kMs;
+    }
+    CHECK(set.IsTrajectoryAtEnd(2) && set.IsTrajectoryAtEnd(4));
+    std::printf("planner set (%s): %zu bytes over PCIe per Plan call at most, %.1f MB on the device\n",
+                skip ? "skip" : "uniform", max_bytes, set.DeviceBytes() / 1e6);
+    for (int k = 0; k < K; k++) tpo_planner_destroy(oracles[k]);
+  }
+}
+
 // SwitchToWaypointPath (timeable_path_joint_spline.cc:209-250) while a plan is being followed,
 // as in the reference's SwitchToNewJointWaypointPathWorks (path_timing_trajectory_test.cc:298-420):
 // plan, switch to a new waypoint path at a parameter ahead of the robot, carry the current
@@ -898,6 +1058,7 @@ int main() {
   TestPlanAgainstOracle();
   TestSwitchPathPlanning();
   TestCartesianSplinePathPlanning();
+  TestPlannerSet();
   if (g_fail == 0) std::printf("ALL OK\n");
   else std::printf("%d CHECKS FAILED\n", g_fail);
   return g_fail == 0 ? 0 : 1;

@@ -14,6 +14,7 @@
 
 #include "tpamd_kernels.h"
 #include "tpamd_launch.h"
+#include "tpamd_planner_set.h"
 #include "tpamd_sweep_joint.h"   // LDS layout, tile size, k_rebuild_time; the kernel instances live in tpamd_sweep_inst.hip
 
 using namespace tpamd;
@@ -1783,5 +1784,363 @@ double tpamd_profile_mean_ms(tpamd_engine *e, int kernel_index, int *num_launche
 
 const char *tpamd_profile_kernel_name(int k) { return (k >= 0 && k < KI_COUNT) ? kKernelNames[k] : ""; }
 int tpamd_profile_num_kernels(void) { return KI_COUNT; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- planner sets
+struct tpamd_planner_set {
+  tpamd_engine *e = nullptr;
+  tpamd_planner_set_config cfg{};
+  int cap = 0, tcap = 0;
+  // fixed-size state (one allocation), history and trajectory (one allocation each: they grow)
+  void *fixed = nullptr, *hist = nullptr, *traj = nullptr;
+  size_t fixed_bytes = 0, hist_bytes = 0, traj_bytes = 0;
+  PlannerSetState S{};
+  PlanParams P{};
+  // device arrays that are not part of S / P
+  double *d_cp = nullptr, *d_vmax = nullptr, *d_delta = nullptr, *d_iv = nullptr, *d_sdd0 = nullptr;
+  double *w_s = nullptr, *w_sd = nullptr, *w_sdd = nullptr, *w_q = nullptr, *w_qd = nullptr, *w_qdd = nullptr,
+         *w_dtm = nullptr, *w_time = nullptr;
+  int32_t *w_lei = nullptr, *w_st = nullptr;
+  int *d_windows = nullptr;
+  long long *d_start = nullptr, *d_horizon = nullptr, *d_loop_start = nullptr;
+  PlannerSummaryDev *d_summary = nullptr;
+  size_t last_h2d = 0, last_d2h = 0;
+};
+
+namespace {
+
+size_t carve_history(char *base, size_t B, size_t cap, size_t D, tpamd_planner_set *ps) {
+  size_t off = 0;
+  auto take = [&](size_t n) { double *p = base ? (double *)(base + off) : nullptr; off = align_up(off + n * 8, 256); return p; };
+  double *t = take(B * cap), *s = take(B * cap), *sd = take(B * cap), *sdd = take(B * cap);
+  double *q = take(B * cap * D), *qd = take(B * cap * D), *qdd = take(B * cap * D);
+  if (ps) {
+    ps->S.h_time = t; ps->S.h_s = s; ps->S.h_sd = sd; ps->S.h_sdd = sdd; ps->S.h_q = q; ps->S.h_qd = qd; ps->S.h_qdd = qdd;
+  }
+  return off;
+}
+size_t carve_trajectory(char *base, size_t B, size_t tcap, size_t D, tpamd_planner_set *ps) {
+  size_t off = 0;
+  auto take = [&](size_t n) { double *p = base ? (double *)(base + off) : nullptr; off = align_up(off + n * 8, 256); return p; };
+  double *t = take(B * tcap), *s = take(B * tcap), *sd = take(B * tcap), *sdd = take(B * tcap);
+  double *q = take(B * tcap * D), *qd = take(B * tcap * D), *qdd = take(B * tcap * D);
+  if (ps) {
+    ps->S.t_time = t; ps->S.t_s = s; ps->S.t_sd = sd; ps->S.t_sdd = sdd; ps->S.t_q = q; ps->S.t_qd = qd; ps->S.t_qdd = qdd;
+  }
+  return off;
+}
+
+// PlanParams view of the set (the window-loop kernels of tpamd_kernels.h)
+void refresh_plan_params(tpamd_planner_set *ps) {
+  PlannerSetState &S = ps->S;
+  PlanParams &p = ps->P;
+  p.B = S.B; p.N = S.N; p.D = S.D; p.K = S.K; p.cap = ps->cap;
+  p.max_iterations = ps->cfg.max_planning_iterations;
+  p.max_initial_velocity_error = ps->cfg.max_initial_velocity_error;
+  p.knots = S.knots; p.delta = ps->d_delta; p.initial_velocity = ps->d_iv;
+  p.start_ns = ps->d_start; p.horizon_ns = ps->d_horizon;
+  p.path_state = S.path_state; p.count = S.count;
+  p.h_time = S.h_time; p.h_s = S.h_s; p.h_sd = S.h_sd; p.h_sdd = S.h_sdd; p.h_q = S.h_q; p.h_qd = S.h_qd; p.h_qdd = S.h_qdd;
+  p.planned_to_end = S.planned_to_end; p.path_horizon = S.path_horizon; p.final_decel_start_ns = S.final_decel_start_ns;
+  p.active = S.active; p.status = S.status; p.windows = ps->d_windows; p.loop_start_ns = ps->d_loop_start;
+  p.num_active = S.num_active;
+  p.path_start = S.path_start; p.sd_start = S.path_start_velocity; p.time_start = S.path_time_start;
+  p.w_time = ps->w_time; p.w_s = ps->w_s; p.w_sd = ps->w_sd; p.w_sdd = ps->w_sdd; p.w_q = ps->w_q; p.w_qd = ps->w_qd;
+  p.w_qdd = ps->w_qdd; p.w_status = ps->w_st; p.w_lei = ps->w_lei;
+  S.cap = ps->cap; S.tcap = ps->tcap;
+}
+
+// Move the histories (or trajectories) to buffers with a larger per-planner capacity.
+int grow_rows(tpamd_planner_set *ps, bool history, int new_cap, hipStream_t st) {
+  const size_t B = ps->S.B, D = ps->S.D;
+  PlannerSetState old = ps->S;
+  void *old_base = history ? ps->hist : ps->traj;
+  const int old_cap = history ? ps->cap : ps->tcap;
+  const size_t need = history ? carve_history(nullptr, B, new_cap, D, nullptr) : carve_trajectory(nullptr, B, new_cap, D, nullptr);
+  void *fresh = nullptr;
+  HIPCHK(hipMalloc(&fresh, need));
+  if (history) { carve_history((char *)fresh, B, new_cap, D, ps); ps->hist = fresh; ps->hist_bytes = need; ps->cap = new_cap; }
+  else { carve_trajectory((char *)fresh, B, new_cap, D, ps); ps->traj = fresh; ps->traj_bytes = need; ps->tcap = new_cap; }
+  const int *first = history ? nullptr : old.t_first;
+  const int *count = history ? old.count : old.t_count;
+  const dim3 g1((old_cap + 255) / 256, (unsigned)B), gD((unsigned)(((size_t)old_cap * D + 255) / 256), (unsigned)B);
+  const double *src1[4] = {history ? old.h_time : old.t_time, history ? old.h_s : old.t_s, history ? old.h_sd : old.t_sd,
+                           history ? old.h_sdd : old.t_sdd};
+  double *dst1[4] = {history ? ps->S.h_time : ps->S.t_time, history ? ps->S.h_s : ps->S.t_s,
+                     history ? ps->S.h_sd : ps->S.t_sd, history ? ps->S.h_sdd : ps->S.t_sdd};
+  const double *srcD[3] = {history ? old.h_q : old.t_q, history ? old.h_qd : old.t_qd, history ? old.h_qdd : old.t_qdd};
+  double *dstD[3] = {history ? ps->S.h_q : ps->S.t_q, history ? ps->S.h_qd : ps->S.t_qd, history ? ps->S.h_qdd : ps->S.t_qdd};
+  for (int k = 0; k < 4; k++)
+    hipLaunchKernelGGL(k_pset_regrow, g1, dim3(256), 0, st, (int)B, old_cap, new_cap, 1, first, count, src1[k], dst1[k]);
+  for (int k = 0; k < 3; k++)
+    hipLaunchKernelGGL(k_pset_regrow, gD, dim3(256), 0, st, (int)B, old_cap, new_cap, (int)D, first, count, srcD[k], dstD[k]);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipFree(old_base));
+  refresh_plan_params(ps);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tpamd_planner_set_create(tpamd_engine *e, const tpamd_planner_set_config *cfg, tpamd_planner_set **out) {
+  if (!e || !cfg || !out) return TPAMD_E_INVALID_ARGUMENT;
+  *out = nullptr;
+  const size_t B = cfg->num_planners, D = cfg->num_dofs, N = cfg->num_samples, P = cfg->num_points;
+  if (cfg->num_planners <= 0 || cfg->time_step_ns <= 0) return TPAMD_E_INVALID_ARGUMENT;
+  if (D < 1 || D > 16 || N < 3 || N > 8192 || P < 3) return TPAMD_E_UNSUPPORTED;
+  if (cfg->sampling_method != 0 && cfg->sampling_method != 1) return TPAMD_E_INVALID_ARGUMENT;
+  TPAMD_ON_DEVICE(e);
+  tpamd_planner_set *ps = new (std::nothrow) tpamd_planner_set();
+  if (!ps) return TPAMD_E_HIP;
+  ps->e = e;
+  ps->cfg = *cfg;
+  ps->cap = cfg->history_capacity > 0 ? std::max<int>(cfg->history_capacity, 2 * (int)N) : 8 * (int)N;
+  ps->tcap = cfg->trajectory_capacity > 0 ? cfg->trajectory_capacity : 4096;
+  const size_t K = P + 3;
+  PlannerSetState &S = ps->S;
+  for (int pass = 0; pass < 2; pass++) {
+    Stage s(pass ? ps->fixed : nullptr);
+    S.knots = s.take<double>(B * K); ps->d_cp = s.take<double>(B * P * D);
+    ps->d_vmax = s.take<double>(B * D); S.amax = s.take<double>(B * D);
+    ps->d_delta = s.take<double>(B); ps->d_iv = s.take<double>(B * D); ps->d_sdd0 = s.take<double>(B);
+    S.path_state = s.take<int>(B); S.has_path = s.take<int>(B); S.count = s.take<int>(B);
+    S.initial_plan = s.take<int>(B); S.planned_to_end = s.take<int>(B); S.target_reached = s.take<int>(B);
+    S.path_horizon = s.take<double>(B); S.path_start = s.take<double>(B); S.path_start_velocity = s.take<double>(B);
+    S.path_time_start = s.take<double>(B);
+    S.start_time_ns = s.take<long long>(B); S.end_time_ns = s.take<long long>(B); S.final_decel_start_ns = s.take<long long>(B);
+    ps->w_time = s.take<double>(B * N); ps->w_s = s.take<double>(B * N); ps->w_sd = s.take<double>(B * N);
+    ps->w_sdd = s.take<double>(B * N); ps->w_q = s.take<double>(B * N * D); ps->w_qd = s.take<double>(B * N * D);
+    ps->w_qdd = s.take<double>(B * N * D); ps->w_dtm = s.take<double>(B);
+    ps->w_lei = s.take<int32_t>(B); ps->w_st = s.take<int32_t>(B);
+    S.t_first = s.take<int>(B); S.t_count = s.take<int>(B);
+    ps->d_start = s.take<long long>(B); ps->d_horizon = s.take<long long>(B); ps->d_loop_start = s.take<long long>(B);
+    S.mode = s.take<int>(B); S.status = s.take<int>(B); S.active = s.take<int>(B); S.finish = s.take<int>(B);
+    S.num_active = s.take<int>(2); S.resample_skip = s.take<int>(B); S.start_sec = s.take<double>(B);
+    S.resample_count = s.take<int>(B);
+    ps->d_windows = s.take<int>(B);
+    ps->P.old_state = s.take<int>(B); ps->P.offset = s.take<int>(B); ps->P.loop = s.take<int>(B); ps->P.append = s.take<int>(B);
+    ps->d_summary = s.take<PlannerSummaryDev>(B);
+    if (!pass) {
+      ps->fixed_bytes = s.off;
+      if (hipMalloc(&ps->fixed, s.off) != hipSuccess) { delete ps; return TPAMD_E_HIP; }
+    }
+  }
+  S.w_time = ps->w_time; S.w_lei = ps->w_lei;
+  S.start_ns = ps->d_start; S.horizon_ns = ps->d_horizon;
+  S.B = (int)B; S.N = (int)N; S.D = (int)D; S.K = (int)K;
+  S.method = cfg->sampling_method; S.max_iterations = cfg->max_planning_iterations;
+  S.time_step_sec = (double)cfg->time_step_ns / 1e9;                    // path_timing_trajectory.cc:206-211
+  S.time_step_duration_ns = (long long)llround(S.time_step_sec * 1e9);  // absl::Seconds(time_step_sec_)
+  ps->hist_bytes = carve_history(nullptr, B, ps->cap, D, nullptr);
+  ps->traj_bytes = carve_trajectory(nullptr, B, ps->tcap, D, nullptr);
+  if (hipMalloc(&ps->hist, ps->hist_bytes) != hipSuccess || hipMalloc(&ps->traj, ps->traj_bytes) != hipSuccess) {
+    tpamd_planner_set_destroy(ps);
+    return TPAMD_E_HIP;
+  }
+  carve_history((char *)ps->hist, B, ps->cap, D, ps);
+  carve_trajectory((char *)ps->traj, B, ps->tcap, D, ps);
+  if (hipMemset(ps->fixed, 0, ps->fixed_bytes) != hipSuccess) { tpamd_planner_set_destroy(ps); return TPAMD_E_HIP; }
+  refresh_plan_params(ps);
+  // ResetDerived :213-227: planned_to_end_ = true (all other scalars zero)
+  std::vector<int> ones(B, 1);
+  if (hipMemcpy(S.planned_to_end, ones.data(), B * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    tpamd_planner_set_destroy(ps);
+    return TPAMD_E_HIP;
+  }
+  *out = ps;
+  return 0;
+}
+
+void tpamd_planner_set_destroy(tpamd_planner_set *ps) {
+  if (!ps) return;
+  DeviceScope scope(ps->e->device);
+  if (ps->fixed) (void)hipFree(ps->fixed);
+  if (ps->hist) (void)hipFree(ps->hist);
+  if (ps->traj) (void)hipFree(ps->traj);
+  delete ps;
+}
+
+size_t tpamd_planner_set_device_bytes(const tpamd_planner_set *ps) {
+  return ps ? ps->fixed_bytes + ps->hist_bytes + ps->traj_bytes : 0;
+}
+
+void tpamd_planner_set_last_plan_bytes(const tpamd_planner_set *ps, size_t *h2d, size_t *d2h) {
+  if (h2d) *h2d = ps ? ps->last_h2d : 0;
+  if (d2h) *d2h = ps ? ps->last_d2h : 0;
+}
+
+int tpamd_planner_set_upload_paths(tpamd_planner_set *ps, int count, const int32_t *ids, const double *knots,
+                                   const double *cps, const double *vmax, const double *amax, const double *delta,
+                                   const double *iv, const int32_t *path_state) {
+  if (!ps || count < 0 || !knots || !cps || !vmax || !amax || !delta || !path_state) return TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = ps->S.B, D = ps->S.D, K = ps->S.K, P = K - 3;
+  if ((size_t)count > B) return TPAMD_E_INVALID_ARGUMENT;
+  TPAMD_ON_DEVICE(ps->e);
+  const int one = 1;
+  std::vector<double> zero(D, 0.0);
+  if (!ids && count > 0) {     // planners 0 .. count-1: one copy per array
+    for (int k = 0; k < count; k++)
+      if (path_state[k] != 1 && path_state[k] != 2) return TPAMD_E_INVALID_ARGUMENT;
+    const size_t n = (size_t)count;
+    std::vector<int> ones(n, 1);
+    std::vector<double> zeros(iv ? 0 : n * D, 0.0);
+    HIPCHK(hipMemcpyAsync((double *)ps->S.knots, knots, n * K * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_cp, cps, n * P * D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_vmax, vmax, n * D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync((double *)ps->S.amax, amax, n * D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_delta, delta, n * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_iv, iv ? iv : zeros.data(), n * D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->S.path_state, path_state, n * 4, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->S.has_path, ones.data(), n * 4, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+  }
+  for (int k = 0; k < count; k++) {
+    const size_t b = ids ? (size_t)ids[k] : (size_t)k;
+    if (b >= B || (path_state[k] != 1 && path_state[k] != 2)) return TPAMD_E_INVALID_ARGUMENT;
+    HIPCHK(hipMemcpyAsync((double *)ps->S.knots + b * K, knots + (size_t)k * K, K * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_cp + b * P * D, cps + (size_t)k * P * D, P * D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_vmax + b * D, vmax + (size_t)k * D, D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync((double *)ps->S.amax + b * D, amax + (size_t)k * D, D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_delta + b, delta + k, 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->d_iv + b * D, iv ? iv + (size_t)k * D : zero.data(), D * 8, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->S.path_state + b, path_state + k, 4, hipMemcpyHostToDevice, nullptr));
+    HIPCHK(hipMemcpyAsync(ps->S.has_path + b, &one, 4, hipMemcpyHostToDevice, nullptr));
+  }
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
+int tpamd_planner_set_reset(tpamd_planner_set *ps, int count, const int32_t *ids) {
+  if (!ps || count < 0) return TPAMD_E_INVALID_ARGUMENT;
+  const size_t B = ps->S.B;
+  TPAMD_ON_DEVICE(ps->e);
+  PlannerSetState &S = ps->S;
+  const int one = 1;
+  const int n = ids ? count : (int)B;
+  for (int k = 0; k < n; k++) {
+    const size_t b = ids ? (size_t)ids[k] : (size_t)k;
+    if (b >= B) return TPAMD_E_INVALID_ARGUMENT;
+    for (int *a : {S.path_state, S.has_path, S.count, S.initial_plan, S.target_reached, S.t_first, S.t_count})
+      HIPCHK(hipMemsetAsync(a + b, 0, 4, nullptr));
+    for (double *a : {S.path_horizon, S.path_start, S.path_start_velocity, S.path_time_start})
+      HIPCHK(hipMemsetAsync(a + b, 0, 8, nullptr));
+    for (long long *a : {S.start_time_ns, S.end_time_ns, S.final_decel_start_ns})
+      HIPCHK(hipMemsetAsync(a + b, 0, 8, nullptr));
+    HIPCHK(hipMemcpyAsync(S.planned_to_end + b, &one, 4, hipMemcpyHostToDevice, nullptr));
+  }
+  HIPCHK(hipStreamSynchronize(nullptr));
+  return 0;
+}
+
+int tpamd_planner_set_plan(tpamd_planner_set *ps, const int64_t *start_ns, const int64_t *horizon_ns,
+                           tpamd_planner_summary *summary) {
+  if (!ps || !start_ns || !horizon_ns) return TPAMD_E_INVALID_ARGUMENT;
+  static_assert(sizeof(tpamd_planner_summary) == sizeof(PlannerSummaryDev), "summary layouts must agree");
+  tpamd_engine *e = ps->e;
+  TPAMD_ON_DEVICE(e);
+  PlannerSetState &S = ps->S;
+  const size_t B = S.B, N = S.N, D = S.D, P = S.K - 3;
+  hipStream_t st = nullptr;
+  ps->last_h2d = ps->last_d2h = 0;
+  HIPCHK(hipMemcpyAsync(ps->d_start, start_ns, B * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ps->d_horizon, horizon_ns, B * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(ps->d_loop_start, start_ns, B * 8, hipMemcpyHostToDevice, st));   // :630
+  ps->last_h2d += 3 * B * 8;
+  for (int *z : {ps->P.old_state, ps->P.offset, ps->P.loop, ps->P.append, ps->d_windows})
+    HIPCHK(hipMemsetAsync(z, 0, B * 4, st));
+  HIPCHK(hipMemsetAsync(S.num_active, 0, 8, st));
+  const unsigned gb = (unsigned)((B + 127) / 128);
+  hipLaunchKernelGGL(k_pset_prologue, dim3(gb), dim3(128), 0, st, S);
+  hipLaunchKernelGGL(k_pset_check_capacity, dim3(gb), dim3(128), 0, st, S);
+  int na[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(na, S.num_active, 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  ps->last_d2h += 8;
+  tpamd_joint_batch bt{(int)B, (int)D, (int)N, (int)P, 0, 0, ps->cfg.constraint_safety};
+  for (int guard = 0; na[0] > 0; guard++) {
+    if (guard > 100000) return TPAMD_E_UNSUPPORTED;
+    if (na[1]) {          // a looping planner's history is full: double the histories, then go on
+      const int rc = grow_rows(ps, /*history=*/true, 2 * ps->cap, st);
+      if (rc) return rc;
+    }
+    tpamd_joint_inputs din{S.knots, ps->d_cp, ps->d_vmax, S.amax, S.path_start, ps->d_delta, S.path_start_velocity,
+                           ps->d_sdd0, S.path_time_start, nullptr};
+    tpamd_path_outputs dout{ps->w_time, ps->w_s, ps->w_sd, ps->w_sdd, ps->w_q, ps->w_qd, ps->w_qdd, ps->w_lei,
+                            ps->w_dtm, ps->w_st, nullptr};
+    hipLaunchKernelGGL(k_plan_begin, dim3(gb), dim3(128), 0, st, ps->P, e->ws);
+    const int rc = solve_joint(e, &bt, &din, &dout, st, &ps->P);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(S.num_active, 0, 8, st));
+    hipLaunchKernelGGL(k_plan_end, dim3(gb), dim3(128), 0, st, ps->P);
+    hipLaunchKernelGGL(k_plan_append, dim3((unsigned)((N + 127) / 128), (unsigned)B), dim3(128), 0, st, ps->P);
+    hipLaunchKernelGGL(k_pset_check_capacity, dim3(gb), dim3(128), 0, st, S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(na, S.num_active, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ps->last_d2h += 8;
+  }
+  // ResampleTrajectory(start) :660 and the bookkeeping of :662-684; repeated with larger trajectory
+  // buffers if a planner's resampled trajectory does not fit
+  for (int attempt = 0; attempt < 8; attempt++) {
+    hipLaunchKernelGGL(k_pset_before_resample, dim3(gb), dim3(128), 0, st, S);
+    ResampleParams rp;
+    rp.B = (int)B; rp.N = ps->cap; rp.D = (int)D; rp.max_out = ps->tcap;
+    rp.time = S.h_time; rp.s = S.h_s; rp.sd = S.h_sd; rp.sdd = S.h_sdd; rp.q = S.h_q; rp.qd = S.h_qd; rp.qdd = S.h_qdd;
+    rp.amax = S.amax; rp.start_sec = S.start_sec; rp.status = S.resample_skip; rp.ns = S.count;
+    rp.ot = S.t_time; rp.os = S.t_s; rp.osd = S.t_sd; rp.osdd = S.t_sdd; rp.oq = S.t_q; rp.oqd = S.t_qd; rp.oqdd = S.t_qdd;
+    rp.count = S.resample_count;
+    if (S.method == 0) {
+      rp.time_step = S.time_step_sec;
+      hipLaunchKernelGGL(k_resample, dim3((ps->tcap + 255) / 256, (unsigned)B), dim3(256), 0, st, rp);
+    } else {
+      if (ps->cap > 32768) return TPAMD_E_UNSUPPORTED;
+      rp.time_step = 0.95 * S.time_step_sec;            // GetMinTimeDeltaToKeep :893-900
+      hipLaunchKernelGGL(k_resample_skip, dim3((unsigned)B), dim3(64), (size_t)ps->cap * 4, st, rp);
+    }
+    HIPCHK(hipMemsetAsync(S.num_active, 0, 8, st));
+    hipLaunchKernelGGL(k_pset_epilogue, dim3(gb), dim3(128), 0, st, S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(na, S.num_active, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ps->last_d2h += 8;
+    if (na[1] <= ps->tcap) break;
+    const int rc = grow_rows(ps, /*history=*/false, std::max(2 * ps->tcap, na[1] + 64), st);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_pset_summary, dim3(gb), dim3(128), 0, st, S, ps->d_windows, ps->d_summary);
+  HIPCHK(hipGetLastError());
+  if (summary) {
+    HIPCHK(hipMemcpyAsync(summary, ps->d_summary, B * sizeof(PlannerSummaryDev), hipMemcpyDeviceToHost, st));
+    ps->last_d2h += B * sizeof(PlannerSummaryDev);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+
+int tpamd_planner_set_download_trajectory(tpamd_planner_set *ps, int planner, int first, int count, double *time,
+                                          double *s, double *sd, double *sdd, double *q, double *qd, double *qdd) {
+  if (!ps || planner < 0 || planner >= ps->S.B || first < 0 || count < 0) return TPAMD_E_INVALID_ARGUMENT;
+  if (count == 0) return 0;
+  TPAMD_ON_DEVICE(ps->e);
+  const PlannerSetState &S = ps->S;
+  int fc[2];
+  HIPCHK(hipMemcpy(&fc[0], S.t_first + planner, 4, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&fc[1], S.t_count + planner, 4, hipMemcpyDeviceToHost));
+  if (first + count > fc[1]) return TPAMD_E_INVALID_ARGUMENT;
+  const size_t o = (size_t)planner * ps->tcap + fc[0] + first, D = S.D, n = count;
+  if (time) HIPCHK(hipMemcpy(time, S.t_time + o, n * 8, hipMemcpyDeviceToHost));
+  if (s) HIPCHK(hipMemcpy(s, S.t_s + o, n * 8, hipMemcpyDeviceToHost));
+  if (sd) HIPCHK(hipMemcpy(sd, S.t_sd + o, n * 8, hipMemcpyDeviceToHost));
+  if (sdd) HIPCHK(hipMemcpy(sdd, S.t_sdd + o, n * 8, hipMemcpyDeviceToHost));
+  if (q) HIPCHK(hipMemcpy(q, S.t_q + o * D, n * D * 8, hipMemcpyDeviceToHost));
+  if (qd) HIPCHK(hipMemcpy(qd, S.t_qd + o * D, n * D * 8, hipMemcpyDeviceToHost));
+  if (qdd) HIPCHK(hipMemcpy(qdd, S.t_qdd + o * D, n * D * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 }  // extern "C"

@@ -1819,6 +1819,7 @@ struct ResampleParams {
   const double *time, *s, *sd, *sdd, *q, *qd, *qdd, *amax, *start_sec;
   double time_step;
   const int32_t *status;
+  const int32_t *ns = nullptr;   // samples of each path (planner histories); null: N. N stays the stride.
   double *ot, *os, *osd, *osdd, *oq, *oqd, *oqdd;
   int32_t *count;
 };
@@ -1828,12 +1829,13 @@ __device__ __forceinline__ double lerp_ref(double t, double a, double b) { retur
 static __global__ void k_resample(ResampleParams p) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int N = p.N, D = p.D;
-  if (p.status && p.status[b] != 0) {
+  const int stride = p.N, D = p.D;
+  const int N = p.ns ? p.ns[b] : p.N;
+  if ((p.status && p.status[b] != 0) || N < 2) {
     if (i == 0) p.count[b] = 0;
     return;
   }
-  const double *tm = p.time + (size_t)b * N;
+  const double *tm = p.time + (size_t)b * stride;
   const double start = p.start_sec[b];
   const double duration = tm[N - 1] - start;
   const int M = (int)(ceil(duration / p.time_step) + 1);
@@ -1857,7 +1859,7 @@ static __global__ void k_resample(ResampleParams p) {
                         ? 0.5
                         : (t - tm[lower]) / (tm[upper] - tm[lower]);
   const size_t ob = (size_t)b * p.max_out + i;
-  const size_t kl = (size_t)b * N + lower, ku = (size_t)b * N + upper;
+  const size_t kl = (size_t)b * stride + lower, ku = (size_t)b * stride + upper;
   p.ot[ob] = t;
   p.os[ob] = lerp_ref(at, p.s[kl], p.s[ku]);
   p.osd[ob] = lerp_ref(at, p.sd[kl], p.sd[ku]);
@@ -1867,7 +1869,7 @@ static __global__ void k_resample(ResampleParams p) {
     const double am = p.amax[(size_t)b * D + d];
     double vq, vqd, vqdd;
     if (last) {
-      vq = p.q[((size_t)b * N + (N - 1)) * D + d];
+      vq = p.q[((size_t)b * stride + (N - 1)) * D + d];
       vqd = 0.0; vqdd = 0.0;
     } else {
       vq = lerp_ref(at, p.q[kl * D + d], p.q[ku * D + d]);
@@ -1893,12 +1895,13 @@ static __global__ void __launch_bounds__(64) k_resample_skip(ResampleParams p) {
   __shared__ int s_count, s_lower;
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
-  const int N = p.N, D = p.D;
-  if (p.status && p.status[b] != 0) {
+  const int stride = p.N, D = p.D;
+  const int N = p.ns ? p.ns[b] : p.N;
+  if ((p.status && p.status[b] != 0) || N < 2) {
     if (lane == 0) p.count[b] = 0;
     return;
   }
-  const double *tm = p.time + (size_t)b * N;
+  const double *tm = p.time + (size_t)b * stride;
   const double start = p.start_sec[b];
   if (lane == 0) {
     // TimeAtPathSamplesLowerIndex (:686-695): first i in [0, N-2] with tm[i+1] > start, else N-1
@@ -1921,7 +1924,7 @@ static __global__ void __launch_bounds__(64) k_resample_skip(ResampleParams p) {
   const int M = s_count, lower = s_lower;
   const int upper = (N - 1 < lower + 1) ? N - 1 : lower + 1;
   const double at = (fabs(tm[upper] - tm[lower]) < DBL_EPSILON) ? 0.5 : (start - tm[lower]) / (tm[upper] - tm[lower]);
-  const size_t pb = (size_t)b * N;
+  const size_t pb = (size_t)b * stride;
   for (int k = lane; k < M && k < p.max_out; k += 64) {
     const size_t ob = (size_t)b * p.max_out + k;
     const bool last_out = (k == M - 1);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.environ.get("TPAMD_LIBRARY") or os.path.join(_CSRC, "libtpamd.so")   # override: A/B builds
 _SOURCES = ["tpamd_capi.hip", "tpamd_sweep_inst.hip", "tpamd_launch.h", "tpamd_kernels.h", "tpamd_device.h",
-            "tpamd_sweep_joint.h"]
+            "tpamd_sweep_joint.h", "tpamd_planner_set.h"]
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "tpamd.h")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared",
@@ -178,6 +178,9 @@ ABI_SYMBOLS = [
     "tpamd_time_cartesian_paths_device", "tpamd_time_cartesian_paths_host",
     "tpamd_sample_pose_splines_device", "tpamd_sample_pose_splines_host",
     "tpamd_plan_joint_windows_host",
+    "tpamd_planner_set_create", "tpamd_planner_set_destroy", "tpamd_planner_set_upload_paths",
+    "tpamd_planner_set_reset", "tpamd_planner_set_plan", "tpamd_planner_set_download_trajectory",
+    "tpamd_planner_set_last_plan_bytes", "tpamd_planner_set_device_bytes",
     "tpamd_find_max_sd2_host", "tpamd_query_device", "tpamd_resample_uniform_device",
     "tpamd_resample_uniform_host", "tpamd_resample_skip_device", "tpamd_resample_skip_host",
     "tpamd_debug_copy_boundary", "tpamd_debug_keep_boundary", "tpamd_debug_copy_diag", "tpamd_debug_kernel_vgprs",
