@@ -283,6 +283,11 @@ def main():
     # of batch k+1.
     compact = args.gather == "compact"
     shared = eng.alloc_joint_outputs(B, N, D, dev, with_q=(args.gather != "full"))
+    # mode 2 lets the sweeps of steps k and k+1 overlap: every output array then exists once per
+    # slot (in the other modes the sweeps run in order on one stream and the arrays that are not
+    # part of the payload are shared)
+    per_slot = [shared, eng.alloc_joint_outputs(B, N, D, dev, with_q=(args.gather != "full")) if mode == 2
+                else shared]
     outs = []
     if compact:
         # flat payload per rank: sd [B][N] | sdd [B][N] | ds [B] | time_start [B]
@@ -310,7 +315,7 @@ def main():
         ds_t = torch.from_numpy(np.ascontiguousarray(ds_h)).to(dev)
         t0_t = torch.as_tensor(np.asarray(batch["time_start"], dtype=np.float64), device=dev)
         for slot in range(2):
-            o = dict(shared)
+            o = dict(per_slot[slot])
             p = G.send[slot]
             o["sd"], o["sdd"] = p[:B * N].view(B, N), p[B * N:2 * B * N].view(B, N)
             p[2 * B * N:2 * B * N + B].copy_(ds_t)
@@ -320,7 +325,7 @@ def main():
         rows = 3 + (D if args.gather == "full" else 0)
         G = shd.PipelinedGather((rows, B, N), torch.float64, dev, depth=2)
         for slot in range(2):
-            o = dict(shared)
+            o = dict(per_slot[slot])
             p = G.send[slot]
             o["time"], o["sd"], o["sdd"] = p[0], p[1], p[2]
             if args.gather == "full":
@@ -352,6 +357,33 @@ def main():
         G.drain()
         first[0] = counter[0]
 
+    def timed_region(steps, with_events):
+        """K steps bracketed by barrier + synchronize on both sides; returns the elapsed seconds."""
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_begin = time.perf_counter()
+        for k in range(steps):
+            E.profile_enable(2 if (with_events and k % stride == 0) else False)
+            step()
+        finish()                          # every batch is solved and its gather has landed on rank 0
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        return time.perf_counter() - t_begin
+
+    timing = not args.no_kernel_timing
+    stride = max(1, args.timing_stride)
+    # Cold figure: the same K steps right after the driver's W warm-up steps, BEFORE the clock
+    # warm-up below -- what a caller sees who starts solving on an idle GPU (about 10 % slower;
+    # reported next to `value` as cold_value / cold_ms_per_step).
+    cold_elapsed = None
+    if args.clock_warmup_ms > 0 and args.steps > 0:
+        for _ in range(args.warmup):
+            step()
+        finish()
+        torch.cuda.synchronize()
+        cold_elapsed = timed_region(args.steps, False)
     # The power management needs sustained load before the clocks settle: a 20-step timed region
     # right after a cold start runs 8 % slower than the same 20 steps after half a second of
     # load (DESIGN.md section 5). Untimed, reported in config.clock_warmup_ms.
@@ -374,22 +406,9 @@ def main():
     finish()
     torch.cuda.synchronize()
 
-    timing = not args.no_kernel_timing
     E.profile_reset()
-    stride = max(1, args.timing_stride)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        # timed region: events around the dominant kernel only, on every stride-th step
-        E.profile_enable(2 if (timing and k % stride == 0) else False)
-        step()
-    finish()                              # every batch is solved and its gather has landed on rank 0
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # timed region: events around the dominant kernel only, on every stride-th step
+    elapsed = timed_region(args.steps, timing)
     E.profile_enable(False)
     # outside the timed region: the root's rebuilt time samples of its OWN shard against the time
     # output of its own solve (same batch every step), bit for bit
@@ -397,9 +416,9 @@ def main():
     if compact and distributed and rank == 0 and counter[0] > 0:
         last = (counter[0] - 1) % 2
         rebuilt_ok = bool(torch.equal(root_time[last][:B].view(torch.int64),
-                                      shared["time"].view(torch.int64)))
+                                      outs[last]["time"].view(torch.int64)))
         if not rebuilt_ok:
-            a, b_ = root_time[last][:B], shared["time"]
+            a, b_ = root_time[last][:B], outs[last]["time"]
             bad = (a.view(torch.int64) != b_.view(torch.int64))
             print("bench.py: rebuilt time differs in %d of %d samples (%d paths), max abs diff %.3e; "
                   "payload ds[0..2] %s, sd equal to local: %s"
@@ -421,12 +440,14 @@ def main():
         torch.cuda.synchronize()
         E.profile_enable(False)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed, cold_elapsed if cold_elapsed is not None else 0.0], dtype=torch.float64, device=dev)
     okt = torch.tensor([ok], dtype=torch.int64, device=dev)
     if distributed:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(okt, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
+    elapsed = float(el[0].item())
+    if cold_elapsed is not None:
+        cold_elapsed = float(el[1].item())
     solved = int(okt.item())
 
     failed = args.steps > 0 and solved != total_paths
@@ -455,6 +476,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
+            # the same K steps right after the W warm-up steps on an idle GPU, before the clock warm-up
+            "cold_value": (round(total_paths * args.steps / cold_elapsed, 1) if cold_elapsed else None),
+            "cold_ms_per_step": (round(cold_elapsed / max(args.steps, 1) * 1e3, 4) if cold_elapsed else None),
             "config": {"workload": "%s: %d random %d-DOF joint-space B-spline paths per GPU, %d "
                                    "s-samples each (10 waypoints, %d control points), inputs "
                                    "resident in HBM" % (what, B, D, N, P),
@@ -470,6 +494,15 @@ def main():
                                         "streams; all K steps complete inside the timed region)"}[mode],
                        "gather": {"mode": args.gather if distributed else "none (single GPU)",
                                   "bytes_per_path": gb,
+                                  # what reaches rank 0, against north_star's "t, s, s', q": q is part of
+                                  # the payload only with --gather full (link-bound at about 4x on 8 GPUs)
+                                  "named_outputs_at_root": (None if not distributed else
+                                                            {"compact": ["sd", "sdd", "t (rebuilt on the root from sd)",
+                                                                         "s (arithmetic sequence from ds)"],
+                                                             "profile": ["t", "sd", "sdd", "s (arithmetic sequence from ds)"],
+                                                             "full": ["t", "sd", "sdd", "q", "s (arithmetic sequence from ds)"]}
+                                                            [args.gather]),
+                                  "north_star_outputs": ["t", "s", "sd", "q"],
                                   "rebuilt_time_equals_local_solve": rebuilt_ok,
                                   "bytes_into_rank0_per_step": gb * B * (world - 1),
                                   "what": (("ONE RCCL gather per step of the packed payload "

@@ -8,6 +8,7 @@
 
 #include "../../oracle/tp_oracle.h"
 #include "../../x-edr-trajectory-planning_amd/host/spline_edit.h"
+#include "../../x-edr-trajectory-planning_amd/host/timeable_path_cartesian_spline.h"
 #include "../../x-edr-trajectory-planning_amd/host/time_optimal_path_timing.h"
 #include "../../x-edr-trajectory-planning_amd/host/timeable_path_joint_spline.h"
 
@@ -240,7 +241,74 @@ static void TestBruteForceLp() {   // time_optimal_path_timing.cc:1010-1103 on t
   }
 }
 
-int main() {
+// The reference's corner-rounding tests for poses (splines/spline_utils_test.cc:31-146) as data:
+// tests/golden/spline_utils_golden.json, flattened to numbers by tests/test_host_cpu.py. The mirror's
+// pose variant (host/timeable_path_cartesian_spline.cc) must reproduce every pinned control pose
+// (translation and rotation about (1, 2, 3) / |(1, 2, 3)|), and the vector variant
+// (TimeableJointSplinePath::PolyLineToControlPoints) the translations of the rotation-free cases.
+static void TestCornerRoundingFixtures(const char *file) {
+  using tpamd::compat::AngleAxisd;
+  using tpamd::compat::Pose3d;
+  using tpamd::compat::Quaterniond;
+  using tpamd::compat::Vector3d;
+  FILE *f = std::fopen(file, "r");
+  CHECK(f != nullptr);
+  if (!f) return;
+  const double an = std::sqrt(14.0);
+  auto make = [&](const double *v) {
+    AngleAxisd aa;
+    aa.axis = Vector3d(1.0 / an, 2.0 / an, 3.0 / an);
+    aa.angle = v[3];
+    return Pose3d(aa.toQuaternion(), Vector3d(v[0], v[1], v[2]));
+  };
+  auto close = [](const Pose3d &a, const Pose3d &b) {
+    double e = 0.0;
+    for (int d = 0; d < 3; d++) e = std::max(e, std::fabs(a.translation()[d] - b.translation()[d]));
+    const Quaterniond &p = a.quaternion(), &q = b.quaternion();
+    const double dot = std::fabs(p.w * q.w + p.x * q.x + p.y * q.y + p.z * q.z);   // q and -q are one rotation
+    return e < 1e-9 && std::fabs(dot - 1.0) < 1e-12;
+  };
+  int ncases = 0, checked = 0;
+  CHECK(std::fscanf(f, "%d", &ncases) == 1);
+  for (int c = 0; c < ncases; c++) {
+    int nc = 0, ncp = 0, nexp = 0;
+    double tr = 0, rr = 0;
+    CHECK(std::fscanf(f, "%d %lf %lf %d", &nc, &tr, &rr, &ncp) == 4);
+    std::vector<Pose3d> corners;
+    std::vector<VectorXd> vec_corners;
+    bool rotation_free = true;
+    for (int i = 0; i < nc; i++) {
+      double v[4];
+      CHECK(std::fscanf(f, "%lf %lf %lf %lf", &v[0], &v[1], &v[2], &v[3]) == 4);
+      corners.push_back(make(v));
+      vec_corners.push_back(VectorXd{v[0], v[1], v[2]});
+      rotation_free = rotation_free && v[3] == 0.0;
+    }
+    std::vector<Pose3d> out;
+    PolyLineToBspline3Waypoints(corners, tr, rr, &out);
+    CHECK((int)out.size() == ncp);
+    for (int i = 0; i < nc && (int)out.size() == ncp && nc > 1; i++) CHECK(close(out[3 * i], corners[i]));
+    if (nc == 1) for (const Pose3d &p : out) CHECK(close(p, corners[0]));
+    std::vector<VectorXd> vout;
+    if (rotation_free) TimeableJointSplinePath::PolyLineToControlPoints(vec_corners, tr, &vout);
+    CHECK(std::fscanf(f, "%d", &nexp) == 1);
+    for (int k = 0; k < nexp; k++) {
+      int idx = 0;
+      double v[4];
+      CHECK(std::fscanf(f, "%d %lf %lf %lf %lf", &idx, &v[0], &v[1], &v[2], &v[3]) == 5);
+      if (idx < (int)out.size()) CHECK(close(out[idx], make(v)));
+      if (rotation_free && idx < (int)vout.size())
+        for (int d = 0; d < 3; d++) CHECK(std::fabs(vout[idx][d] - v[d]) < 1e-9);
+      checked++;
+    }
+    if (nc == 2 && tr == 0.0) { CHECK(close(out[1], corners[0])); CHECK(close(out[2], corners[1])); }   // ZeroRadius
+  }
+  std::fclose(f);
+  CHECK(ncases == 5 && checked == 10);
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1) TestCornerRoundingFixtures(argv[1]);
   TestInsertKnot();
   TestTruncate();
   TestExtend();

@@ -247,3 +247,53 @@ def test_unpipelined_solves_between_pipelined_ones_share_the_workspace_safely(en
             assert torch.equal(got1[name][k], ref[name][k]), (name, k)
     assert (ref["r"]["status"] == 0).all() and (ref["c"]["status"] == 0).sum() > 80
     E1.close(); E2.close()
+
+
+def test_config3_full_size_properties(env):
+    """BASELINE.json configs[3] at its stated size -- 4096 Cartesian 6-joint paths of 2000 samples,
+    one engine call: size-independent properties on EVERY path (monotone time, rest to rest, joint
+    and Cartesian speed limits, the IK positions passed through), bit parity with the oracle on a
+    strided subset, and a second solve that reproduces the first."""
+    torch, eng, syn, tpo, E = (env[k] for k in ("torch", "eng", "syn", "tpo", "E"))
+    B, D, N = 4096, 6, 2000
+    b = syn.make_cartesian_batch(B, D, N)
+    inp = syn.upload_cartesian_batch(b, env["dev"])
+    out = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    E.time_cartesian_paths(inp, out)
+    torch.cuda.synchronize()
+    st = out["status"].cpu().numpy()
+    assert (st == 0).all()
+    t = out["time"].cpu().numpy(); s = out["s"].cpu().numpy()
+    sd = out["sd"].cpu().numpy(); sdd = out["sdd"].cpu().numpy()
+    qd = out["qd"].cpu().numpy(); qdd = out["qdd"].cpu().numpy()
+    assert np.isfinite(t).all() and np.isfinite(sd).all() and np.isfinite(sdd).all()
+    assert (np.diff(t, axis=1) >= 0).all() and (t[:, 0] == 0).all()
+    assert (sd[:, 0] == 0).all() and (sd[:, -1] == 0).all() and (sd >= 0).all()
+    assert (s[:, 0] == 0).all()
+    np.testing.assert_array_equal(s[:, -1], b["delta"] * (N - 1))
+    assert torch.equal(out["q"], inp["ik_positions"])
+    assert (np.abs(qd) <= 0.8 * b["vmax"][:, None, :] * (1 + 1e-9) + 1e-12).all()
+    assert (np.abs(qdd) <= b["amax"][:, None, :]).all()
+    # the two Cartesian rows: |(J q')_{1..3}|^2 sd^2 <= v_trans^2, |(J q')_{4..6}|^2 sd^2 <= v_rot^2
+    # (no safety factor on them, timeable_path_cartesian_spline.cc:578-592), in blocks of paths
+    for lo in range(0, B, 512):
+        q = b["ik_positions"][lo:lo + 512]
+        q1 = np.zeros_like(q)
+        q1[:, :-1] = (q[:, 1:] - q[:, :-1]) / b["delta"][lo:lo + 512, None, None]
+        v6 = np.einsum("bnrd,bnd->bnr", b["jacobians"][lo:lo + 512], q1)
+        sd2 = sd[lo:lo + 512] ** 2
+        assert ((v6[..., :3] ** 2).sum(-1) * sd2 <= (b["vtrans"][lo:lo + 512, None] ** 2) * (1 + 1e-6) + 1e-9).all()
+        assert ((v6[..., 3:] ** 2).sum(-1) * sd2 <= (b["vrot"][lo:lo + 512, None] ** 2) * (1 + 1e-6) + 1e-9).all()
+    sel = slice(0, B, 131)
+    ref = tpo.time_cartesian_batch(b["ik_positions"][sel], b["jacobians"][sel], b["vmax"][sel], b["amax"][sel],
+                                   b["vtrans"][sel], b["vrot"][sel], b["path_start"][sel], b["delta"][sel],
+                                   nthreads=16)
+    assert (ref["status"] == 0).all()
+    for k, g in (("t", t), ("s", s), ("sd", sd), ("sdd", sdd), ("qd", qd), ("qdd", qdd)):
+        np.testing.assert_array_equal(g[sel], ref[k], err_msg=k)
+    np.testing.assert_array_equal(out["last_extremal_index"].cpu().numpy()[sel], ref["last_extremal_index"])
+    again = eng.alloc_joint_outputs(B, N, D, env["dev"])
+    E.time_cartesian_paths(inp, again)
+    torch.cuda.synchronize()
+    for k in ("time", "sd", "sdd", "qd", "qdd", "status"):
+        assert torch.equal(again[k], out[k]), k

@@ -126,3 +126,31 @@ def test_polyline_corner_rounding_structure():
     np.testing.assert_allclose(short[:, 0], [0.0, 0.1, 0.3, 0.4])
     one = tpo.polyline_to_bspline3_waypoints(np.array([[1.0, 2.0]]), 0.2)
     assert one.shape == (4, 2) and np.all(one == [1.0, 2.0])
+
+
+def test_polyline_corner_rounding_reference_fixtures(golden_dir):
+    """The literal corners and control points of the reference's corner-rounding tests
+    (tests/golden/spline_utils_golden.json, mined from splines/spline_utils_test.cc:31-146). The
+    oracle restates the vector variant (spline_utils.cc:47-102): on the cases without rotation the
+    pose variant (:104-204) places its control points at the same translations."""
+    import json
+    import os
+    fx = json.load(open(os.path.join(golden_dir, "spline_utils_golden.json")))
+    used = 0
+    for case in fx["cases"]:
+        if any(c["angle"] != 0.0 for c in case["corners"]):
+            continue
+        corners = np.array([c["translation"] for c in case["corners"]])
+        out = tpo.polyline_to_bspline3_waypoints(corners, case["translation_radius"])
+        assert out.shape == (case["num_control_points"], 3)
+        if len(corners) == 1:                 # OneCorner: the corner four times
+            assert (out == corners[0]).all()
+        else:
+            np.testing.assert_array_equal(out[0::3], corners)
+        for idx, pose in case["expected"].items():
+            np.testing.assert_allclose(out[int(idx)], pose["translation"], atol=1e-9, err_msg=case["name"])
+        if case["name"] == "ZeroRadius":      # the extra control points sit on the corners
+            np.testing.assert_array_equal(out[1], corners[0])
+            np.testing.assert_array_equal(out[2], corners[1])
+        used += 1
+    assert used == 4

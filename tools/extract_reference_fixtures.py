@@ -120,6 +120,51 @@ def extract_lp_regression():
     print("lp_regression.json: %d cases" % len(cases))
 
 
+def extract_spline_utils_cases():
+    """PolyLineToBspline3WaypointsPosesTest (splines/spline_utils_test.cc:31-146): the literal
+    corners, radii and expected control poses of the corner-rounding tests. Poses are stored as
+    (translation | rotation angle about the axis (1, 2, 3) / |(1, 2, 3)|), the two forms the tests
+    use; numbers only."""
+    src = open(os.path.join(REF, "splines", "spline_utils_test.cc")).read()
+    cases = []
+    for name in ("OneCorner", "Translation", "Rotation", "RadiusOutOfBounds", "ZeroRadius"):
+        m = re.search(r"TEST\(PolyLineToBspline3WaypointsPosesTest, %s\)\s*\{(.*?)\n\}" % name, src, re.S)
+        assert m, name
+        body = m.group(1)
+        corners = []
+        for st in re.findall(r"corners\.emplace_back\((.*?)\);", body, re.S):
+            a = re.search(r"AngleAxis<double>\(\s*(%s)," % NUM, st)
+            v = re.search(r"Vector3d\((%s), (%s), (%s)\)" % (NUM, NUM, NUM), st)
+            if a:
+                corners.append({"translation": [0.0, 0.0, 0.0], "angle": float(a.group(1))})
+            else:
+                corners.append({"translation": [float(v.group(i)) for i in (1, 2, 3)], "angle": 0.0})
+        radii = re.search(r"kTranslationalRadius = (%s);.*?kRotationalRadius = (%s);" % (NUM, NUM), body, re.S)
+        if radii:
+            tr, rr = float(radii.group(1)), float(radii.group(2))
+        else:
+            tr, rr = 0.0, 0.0          # OneCorner passes literal zeros
+        expected = {}
+        for mm in re.finditer(r"Pose3d cp_(\d)\((.*?)\);", body, re.S):
+            a = re.search(r"AngleAxis<double>\(\s*(%s)," % NUM, mm.group(2))
+            v = re.search(r"Vector3d\((%s), (%s), (%s)\)" % (NUM, NUM, NUM), mm.group(2))
+            if a:
+                expected[mm.group(1)] = {"translation": [0.0, 0.0, 0.0], "angle": float(a.group(1))}
+            else:
+                expected[mm.group(1)] = {"translation": [float(v.group(i)) for i in (1, 2, 3)], "angle": 0.0}
+        count = int(re.search(r"ASSERT_EQ\((\d+), control_points\.size\(\)\)", body).group(1))
+        cases.append({"name": name, "corners": corners, "translation_radius": tr, "rotation_radius": rr,
+                      "num_control_points": count, "expected": expected})
+    fixture = {"source": "trajectory_planning/splines/spline_utils_test.cc:31-146",
+               "rotation_axis": [1.0, 2.0, 3.0],
+               "rule": "control point 3i = corner i; 'expected' lists the other control points the tests pin "
+                       "(ZeroRadius: 1 = corner 0, 2 = corner 1; OneCorner: all four = the corner)",
+               "tolerance": "eigenmath IsApprox (1e-9 absolute used here)", "cases": cases}
+    with open(os.path.join(OUT, "spline_utils_golden.json"), "w") as f:
+        json.dump(fixture, f, indent=1)
+    print("spline_utils_golden.json: %d cases" % len(cases))
+
+
 if __name__ == "__main__":
     extract_quat_exp_tables()
     if not os.path.isdir(REF):
@@ -127,3 +172,4 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     extract_bspline_tables()
     extract_lp_regression()
+    extract_spline_utils_cases()
