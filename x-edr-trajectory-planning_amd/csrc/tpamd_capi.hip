@@ -164,9 +164,20 @@ int ensure_workspace(tpamd_engine *e, int B, int N, int C) {
     e->ws_bytes = 0;
     HIPCHK(hipMalloc(&e->ws_base, need));
     e->ws_bytes = need;
+#ifdef TPAMD_K1_STUDY
+    HIPCHK(hipMemset(e->ws_base, 0, need));
+#endif
   }
   carve_workspace((char *)e->ws_base, B, N, C, &e->ws);
   e->ws.keep_boundary = e->keep_boundary ? 1 : 0;
+#ifdef TPAMD_K1_STUDY
+  {   // study build: both workspace slots share one timestamp buffer; the slot goes along in bit 1
+    static void *g_study = nullptr;
+    if (!g_study) { HIPCHK(hipMalloc(&g_study, 65536 * 8)); HIPCHK(hipMemset(g_study, 0, 65536 * 8)); }
+    e->ws.diag = (long long *)g_study;
+    e->ws.keep_boundary |= (e->slot & 1) << 1;
+  }
+#endif
   return 0;
 }
 

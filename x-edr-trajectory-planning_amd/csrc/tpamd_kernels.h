@@ -223,6 +223,19 @@ __device__ __forceinline__ void sample_lp_joint_body(int N, int D_rt, int P, con
                                                      const double *cps_g, double *q_out,
                                                      const Workspace &ws) {
   extern __shared__ double lds[];
+#ifdef TPAMD_K1_PRIO
+  __builtin_amdgcn_s_setprio(TPAMD_K1_PRIO);   // A/B: instruction-issue priority of this kernel's waves
+#endif
+#ifdef TPAMD_K1_STUDY
+  // study build: start / end clock of every block of this kernel (ws.diag[2 * block], [2 * block + 1])
+  if (threadIdx.x == 0) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    reinterpret_cast<unsigned long long *>(ws.diag)[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = t | ((unsigned long long)(xcc & 15u) << 60);
+  }
+#endif
   const int TPB = blockDim.x;
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -315,10 +328,23 @@ __device__ __forceinline__ void sample_lp_joint_body(int N, int D_rt, int P, con
   } else {
     boundary_point<WORDS, true>(r, C, o, ws);
   }
+#ifdef TPAMD_K1_STUDY
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    reinterpret_cast<unsigned long long *>(ws.diag)[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = t;
+  }
+#endif
 }
 
+#ifdef TPAMD_K1_STUDY   // (the stamps must not change the register footprint the study is about)
+#define TPAMD_K1_STUDY_REGS __attribute__((amdgpu_waves_per_eu(5, 5)))
+#else
+#define TPAMD_K1_STUDY_REGS
+#endif
 template <int WORDS, int DT>
-__global__ void k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
+__global__ void TPAMD_K1_STUDY_REGS k_sample_lp_joint(int N, int D_rt, int P, const double *knots_g,
                                   const double *cps_g, double *q_out, Workspace ws) {
   sample_lp_joint_body<WORDS, DT>(N, D_rt, P, knots_g, cps_g, q_out, ws);
 }

@@ -193,7 +193,11 @@ __device__ __forceinline__ long long tpamd_stamp() {
   return (long long)t;
 }
 #define TPAMD_T0(var) const long long var = tpamd_stamp()
+#ifdef TPAMD_DIAG_REASONS   // (study build: slots 12, 13, 17, 19..23, 31 count why chain blocks end instead)
+#define TPAMD_ACC(slot, var) do { if (!((slot) == 12 || (slot) == 13 || (slot) == 17 || ((slot) >= 19 && (slot) <= 23) || (slot) == 31)) diag[slot] += tpamd_stamp() - (var); } while (0)
+#else
 #define TPAMD_ACC(slot, var) diag[slot] += tpamd_stamp() - (var)
+#endif
 #define TPAMD_CNT(slot) diag[slot] += 1
 #define TPAMD_ADD(slot, v) diag[slot] += (v)
 #else
@@ -205,6 +209,11 @@ __device__ __forceinline__ long long tpamd_stamp() {
 
 #ifndef TPAMD_TILE_SAMPLES
 #define TPAMD_TILE_SAMPLES 32
+#endif
+// After a speculative block that ended because the active constraint changed, speculate on the
+// constraint that took over instead of finding it with a scalar FindSdd step (A/B: 0 = off).
+#ifndef TPAMD_CHAIN_GUESS
+#define TPAMD_CHAIN_GUESS 1
 #endif
 constexpr int kTileSamples = TPAMD_TILE_SAMPLES;   // largest tile (the engine pads the records by one)
 // Samples per tile of the D-joint sweep: wide records (D > 8: 30 doubles at D = 14) take 16-sample
@@ -300,7 +309,7 @@ struct JointSweep {
   // pass. During the boundary passes 10 / 11 count the re-fits of the final / the first pass
   // (the sweep then counts on top: scalar FindSdd steps / loops).
   // 24 scalar-step cycles, 25 boundary-follow cycles, 26 init_carry cycles, 27 tile fills, 28 tile-fill
-  // cycles, 29 init_carry calls
+  // cycles, 29 init_carry calls, 30 blocks started from a guessed constraint
   long long diag[32];
 #endif
   int N, lane;
@@ -592,16 +601,22 @@ struct JointSweep {
 #pragma unroll
     for (int i = 0; i < L::CPL; i++) o.rc[i] = __builtin_amdgcn_rcp(o.pown[i].x);
   }
+  // `guess` (in: -1): the candidate (2 * row + bound) that this lane's failed check points at as the
+  // NEXT active constraint -- the bound of an acceleration row the speculated candidate violates,
+  // or another candidate that compares better and does not violate the speculated row. Only a hint
+  // for the next block's speculation (see add_extremal); never part of a result.
   template <bool MAX>
   __device__ __forceinline__ bool chain_step_bad(const ChainOperands &o, int win_cand, double hi_r,
-                                                 f64x2 arow, double s2, double sddw) const {
+                                                 f64x2 arow, double s2, double sddw, int &guess) const {
     bool bad = false;
 #pragma unroll
     for (int i = 0; i < L::VPL; i++) {       // winner against this lane's share of the rows
       const f64x2 pr = o.pvv[i];
       // (v + kTiny < -hi) | (v - kTiny > hi) as one comparison, see find_sdd_both_joint_fixed
       const double v = pr.x * sddw + pr.y * s2;
-      bad = bad | (fabs(v) - kTiny > va_hi[i]);
+      const bool viol = fabs(v) - kTiny > va_hi[i];
+      bad = bad | viol;
+      if (viol) guess = 2 * vv_off[i] + (v > 0.0 ? 1 : 0);
       // velocity row: q'^2 sd2 >= 0 here (a step whose sd2 is negative is never accepted: the
       // step before it is flagged), so only the upper bound can fail
       const double vv = (pr.x * pr.x) * s2;
@@ -632,7 +647,9 @@ struct JointSweep {
       const double ax = arow.x * sa;
       const double va = ax + bs_r;
       const bool violates = __builtin_fma(-2e-6, fabs(ax), fabs(va) * (1.0 - 1e-12)) > row_limit;
-      bad = bad | !(skip | not_better | violates);
+      const bool beats = !(skip | not_better | violates);
+      bad = bad | beats;
+      if (beats) guess = p0 + L::GRP * i;
     }
     return bad;
   }
@@ -854,10 +871,13 @@ struct JointSweep {
   // if steps 0..k-1 verified, so the leading block of verified steps is exactly what the
   // scalar steps would have produced; it is committed, anything after it is discarded and
   // redone by the scalar step. Returns the number of steps taken (0..16).
+  // next_win: where a block ended short of K steps because the active constraint changed, the lane
+  // (find_sdd layout) of the candidate that took over at the first unverified step, else -1.
   template <bool FWD>
-  __device__ __forceinline__ int follow_chain(Carry &c, Prefetch &pf) {
+  __device__ __forceinline__ int follow_chain(Carry &c, Prefetch &pf, int &next_win) {
     constexpr int dir = FWD ? 1 : -1;
     constexpr int K = L::kChain;
+    next_win = -1;
     const int wl = c.win;
     const int r = (wl / L::PARTS) >> 1;                  // row of the speculated candidate
     const double alim = readlane_f64(lim, wl);           // its bound
@@ -927,7 +947,8 @@ struct JointSweep {
     const double my_new = FWD ? my_cur + two_ds * my_sdd : my_cur - two_ds * my_sdd;
     const double chain_next = y_out;                     // what the chain fed to step k+1
     const bool bits_equal = __double_as_longlong(chain_next) == __double_as_longlong(my_new);
-    const bool bad = chain_step_bad<FWD>(ops, wl / L::PARTS, hi_r, arow, my_cur, my_sdd);
+    int guess = -1;
+    const bool bad = chain_step_bad<FWD>(ops, wl / L::PARTS, hi_r, arow, my_cur, my_sdd, guess);
     const int t_j = __double2loint(mt_j.y), t_n = __double2loint(mt_n.y);
     const double m_j = mt_j.x, m_n = mt_n.x;
     const bool riding = is_tiny(my_cur - m_j) & ((t_j & kBndTrajectory) != 0) & ((t_n & kBndTrajectory) != 0);
@@ -939,6 +960,30 @@ struct JointSweep {
     if (G >= 4) fm |= fm >> 2;
     const unsigned long long miss = fm & L::kPart0;     // bit 4k: step k failed
     const int Lc = miss ? ((__ffsll((long long)miss) - 1) / G) : K;
+#ifdef TPAMD_DIAG_REASONS
+    if (Lc < K) {
+      const unsigned long long lanes_ = ((1ull << G) - 1ull) << (G * Lc);
+      const bool r_loop = (__ballot(!in_loop) & lanes_) != 0, r_eq = (__ballot(!bits_equal) & lanes_) != 0;
+      const bool r_ride = (__ballot(riding) & lanes_) != 0, r_isect = (__ballot(!isnan(nxt) & (nxt < my_new)) & lanes_) != 0;
+      const bool r_curve = (__ballot(my_new > m_n) & lanes_) != 0, r_neg = (__ballot((my_new < 0) | isnan(my_new)) & lanes_) != 0;
+      const bool r_bad = (__ballot(bad) & lanes_) != 0, r_hint = (__ballot(guess >= 0) & lanes_) != 0;
+      if (r_loop) diag[19]++; else if (r_ride) diag[20]++; else if (r_isect) diag[21]++; else if (r_curve) diag[22]++;
+      else if (r_neg) diag[23]++; else if (r_eq) diag[31]++; else if (r_bad && r_hint) diag[13]++; else if (r_bad) diag[12]++;
+      if (Lc == 0) diag[17]++;
+    }
+#endif
+    if (TPAMD_CHAIN_GUESS && Lc > 0 && Lc < K) {
+      // Why did step Lc fail? If only because another constraint became active (no special case of
+      // the scalar step, the chain value itself was right), its lanes know which one: the next
+      // block can start from it without a scalar FindSdd step in between.
+      const unsigned long long other = __ballot(!in_loop | !bits_equal | special);
+      const unsigned long long hints = __ballot(guess >= 0);
+      const unsigned long long lanes = ((1ull << G) - 1ull) << (G * Lc);
+      if ((other & lanes) == 0ull && (hints & lanes) != 0ull) {
+        const int src = __ffsll((long long)(hints & lanes)) - 1;
+        next_win = __builtin_amdgcn_readlane(guess, src) * L::PARTS;
+      }
+    }
     if (Lc == 0) return 0;
     if ((lane & (G - 1)) == 0 && k < Lc) {
       sd2[j + dir] = my_new;
@@ -1032,12 +1077,16 @@ struct JointSweep {
 // steps selecting the same candidate to try again.
 #define TPAMD_TRY_CHAIN()                                                                    \
   if (c.win >= 0 && (trust || c.win == last_win)) {                                          \
-    int total = 0, run;                                                                      \
+    int total = 0, run, next_win;                                                            \
+    bool again;                                                                              \
     do {                                                                                     \
-      { TPAMD_T0(tc_); run = uniform_i32(follow_chain<FWD>(c, pf)); TPAMD_ACC(4, tc_); }     \
+      { TPAMD_T0(tc_); run = uniform_i32(follow_chain<FWD>(c, pf, next_win)); TPAMD_ACC(4, tc_); } \
       TPAMD_CNT(6);                                                                          \
       total += run;                                                                          \
-    } while (run == L::kChain && (FWD ? (c.idx < N - 2) : (c.idx > 1)));                     \
+      again = run == L::kChain;                                                              \
+      /* the active constraint changed inside the block: go on with the one that took over */ \
+      if (run > 0 && run < L::kChain && next_win >= 0) { c.win = uniform_i32(next_win); again = true; TPAMD_CNT(30); } \
+    } while (again && (FWD ? (c.idx < N - 2) : (c.idx > 1)));                                \
     trust = total > 0;                                                                       \
     last_win = -1;                                                                           \
     if (total > 0) {                                                                         \
@@ -1718,8 +1767,13 @@ __host__ __device__ inline size_t sweep_joint_lds_bytes(int N) {
 #define TPAMD_SWEEP_OCCUPANCY                                                                          \
   __attribute__((amdgpu_waves_per_eu((D > 8) ? TPAMD_SWEEP_WAVES_PER_EU_WIDE : TPAMD_SWEEP_WAVES_PER_EU, \
                                      (D > 8) ? TPAMD_SWEEP_WAVES_PER_EU_WIDE : TPAMD_SWEEP_WAVES_PER_EU)))
+#ifdef TPAMD_K1_STUDY
+#define TPAMD_SWEEP_STUDY_REGS __attribute__((amdgpu_num_vgpr(200)))
+#else
+#define TPAMD_SWEEP_STUDY_REGS
+#endif
 template <int D, int E = 0>
-__global__ void __launch_bounds__(128) TPAMD_SWEEP_OCCUPANCY
+__global__ void __launch_bounds__(128) TPAMD_SWEEP_OCCUPANCY TPAMD_SWEEP_STUDY_REGS
 k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *t_out, double *s_out,
               double *sd_out, double *sdd_out, int32_t *lei_out, double *dtmax_out,
               int32_t *status_out, double *qd_out, double *qdd_out) {
@@ -1742,6 +1796,17 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     }
     return;
   }
+#ifdef TPAMD_K1_STUDY
+  // study build: start / end clock of every sweep workgroup, per workspace slot
+  unsigned long long *study = reinterpret_cast<unsigned long long *>(ws.diag) + 40960 + ((ws.keep_boundary >> 1) & 1) * 4096;
+  if (tid == 0) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    study[2 * b] = t | ((unsigned long long)(xcc & 15u) << 60);
+  }
+#endif
   JS S;
   S.N = N; S.lane = lane;
   S.ds = ws.ds[b];
@@ -1779,7 +1844,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   // (flags in the sd2 array, re-fit values in the tile rings)
   boundary_passes_for_path<D, E>(src, ws, b, N, stride, tid, reinterpret_cast<uint8_t *>(sd2),
                            reinterpret_cast<uint8_t *>(sd2) + LL::type_bytes(N),
-                           reinterpret_cast<char *>(ring), typel, ws.keep_boundary != 0,
+                           reinterpret_cast<char *>(ring), typel, (ws.keep_boundary & 1) != 0,
                            TPAMD_DIAG_PTR);
   // (the boundary passes run before the per-lane constants below are loaded: they need most of
   // the register file for themselves)
@@ -2273,6 +2338,13 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     status_out[b] = 0;
     if (dtmax_out) dtmax_out[b] = (red[0] > red[1]) ? red[0] : red[1];
   }
+#ifdef TPAMD_K1_STUDY
+  if (tid == 0) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    study[2 * b + 1] = t;
+  }
+#endif
   TPAMD_ACC(3, t_tail);
   TPAMD_ACC(15, t_all);
 #ifdef TPAMD_DIAG
