@@ -32,6 +32,32 @@ def test_header_symbols_are_all_exported(eng):
     assert lib.tpamd_error_string(7).decode().startswith("could not connect")
 
 
+def test_multi_device_header_symbols_are_all_exported(eng):
+    """include/tpamd_multi.h against libtpamd_multi.so (loads RCCL; no device call)."""
+    hdr = open(os.path.join(ROOT, "include", "tpamd_multi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tpamd_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == {"tpamd_multi_create", "tpamd_multi_destroy", "tpamd_multi_num_devices", "tpamd_multi_device",
+                        "tpamd_multi_engine", "tpamd_multi_uses_rccl", "tpamd_gather_bytes_per_path",
+                        "tpamd_multi_time_joint_paths_host", "tpamd_multi_time_joint_groups_host"}
+    eng.load_library()
+    lib = ctypes.CDLL(eng.build_multi_library())
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    lib.tpamd_gather_bytes_per_path.restype = ctypes.c_size_t
+    assert lib.tpamd_gather_bytes_per_path(0, 2000, 7) == 32016      # compact: 16 N + 16
+    assert lib.tpamd_gather_bytes_per_path(2, 2000, 7) == 160000     # full: north_star's t, sd, sdd... + q
+
+
+def test_planner_set_struct_layouts_match_header(eng):
+    class Cfg(ctypes.Structure):
+        _fields_ = [(n, ctypes.c_int32) for n in ("a", "b", "c", "d", "e", "f", "g", "h")] + \
+                   [("x", ctypes.c_double), ("y", ctypes.c_double), ("z", ctypes.c_int64)]
+    assert ctypes.sizeof(Cfg) == 56                                   # tpamd_planner_set_config
+    # tpamd_planner_summary: 3 x int64 + 8 x int32 (the device-side record has the same layout)
+    assert 3 * 8 + 8 * 4 == 56
+
+
 def test_struct_layouts_match_header(eng):
     # sizes implied by the C declarations (LP64): 6 int32 + double; 9 / 10 pointers; ...
     assert ctypes.sizeof(eng._JointBatch) == 32

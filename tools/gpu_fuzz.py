@@ -58,14 +58,56 @@ def main():
         if time.time() >= next_note:      # a progress line every half minute
             print("[fuzz] %d cases, %d paths, %d failures" % (cases, paths, len(failures)), file=sys.stderr, flush=True)
             next_note += 30.0
-        kind = rng.choice(["joint", "joint", "ragged", "cartesian"])
+        kind = rng.choice(["joint", "joint", "ragged", "cartesian", "groups"])
         D = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 7, 7, 8, 9, 12, 14, 16]))
-        N = int(rng.choice([3, 4, 17, 63, 64, 65, 128, 500, 1000, 2000, 2999]))
+        N = int(rng.choice([3, 4, 17, 63, 64, 65, 128, 500, 1000, 2000, 2108, 2109, 2999, 4000, 4217, 6000]))
         B = int(rng.integers(1, 65))
         W = int(rng.choice([2, 3, 5, 10]))
         first = int(rng.integers(0, 1 << 30))
         desc = dict(kind=str(kind), D=D, N=N, B=B, W=W, first=first)
-        if kind == "cartesian":
+        if kind == "groups":
+            # several batches of different shape side by side on the engine's lanes
+            # (tpamd_time_joint_groups_device), some of them ragged: each against its own oracle run
+            G = int(rng.integers(2, 6))
+            groups, refs, cnts = [], [], []
+            for g in range(G):
+                Dg = int(rng.choice([3, 6, 7, 7, 14, 5, 9]))
+                Ng = int(rng.choice([17, 128, 500, 1000, 2000, 2500, 4000]))
+                Bg = int(rng.integers(1, 33))
+                bg = syn.make_joint_batch(Bg, Dg, Ng, num_waypoints=W, first_path_index=first + 1000 * g)
+                bg["vmax"] = bg["vmax"] * rng.uniform(0.3, 3.0, (Bg, 1))
+                ragged = Ng >= 6 and rng.uniform() < 0.5
+                counts = rng.integers(3, Ng + 1, size=Bg).astype(np.int32) if ragged else None
+                if ragged:
+                    bg["delta"] = bg["knots"][:, -1] / (counts - 1)
+                ig = eng.upload_joint_batch(bg, DEV)
+                if ragged:
+                    ig["num_samples_per_path"] = torch.from_numpy(counts).to(DEV)
+                groups.append(dict(inputs=ig, outputs=eng.alloc_joint_outputs(Bg, Ng, Dg, DEV), num_samples=Ng))
+                if ragged:
+                    ref = dict(status=np.zeros(Bg, np.int32), last_extremal_index=np.zeros(Bg, np.int32),
+                               **{k: [None] * Bg for k in ("t", "s", "sd", "sdd", "qd", "qdd")})
+                    for i in range(Bg):
+                        one = {k: bg[k][i:i + 1] for k in ("knots", "control_points", "vmax", "amax", "path_start", "delta")}
+                        r1 = tpo.time_joint_batch(one["knots"], one["control_points"], one["vmax"], one["amax"],
+                                                  one["path_start"], one["delta"], int(counts[i]))
+                        ref["status"][i] = r1["status"][0]
+                        ref["last_extremal_index"][i] = r1["last_extremal_index"][0]
+                        for k in ("t", "s", "sd", "sdd", "qd", "qdd"):
+                            ref[k][i] = r1[k][0]
+                else:
+                    ref = tpo.time_joint_batch(bg["knots"], bg["control_points"], bg["vmax"], bg["amax"],
+                                               bg["path_start"], bg["delta"], Ng, nthreads=16)
+                refs.append(ref)
+                cnts.append(counts)
+                paths += Bg
+            E.time_joint_groups(groups)
+            torch.cuda.synchronize()
+            bad = None
+            for g in range(G):
+                bad = bad or check(groups[g]["outputs"], refs[g], cnts[g])
+            paths -= B
+        elif kind == "cartesian":
             D = min(D, 9)
             N = max(N, 3)
             b = syn.make_cartesian_batch(B, D, N, num_waypoints=W, first_path_index=first)

@@ -211,9 +211,12 @@ __device__ __forceinline__ long long tpamd_stamp() {
 #define TPAMD_TILE_SAMPLES 32
 #endif
 // After a speculative block that ended because the active constraint changed, speculate on the
-// constraint that took over instead of finding it with a scalar FindSdd step (A/B: 0 = off).
+// constraint that took over instead of finding it with a scalar FindSdd step. Measured (round 3):
+// scalar steps per path 97 -> 89 and the mean path 2 % shorter in cycles, but 2.4 M VALU instructions
+// more per launch (the hint bookkeeping of every block) -- the step, which is bound by the instruction
+// count, got 0.5 % (pipelined) to 1.8 % (one kernel at a time) slower. Off; kept for the record.
 #ifndef TPAMD_CHAIN_GUESS
-#define TPAMD_CHAIN_GUESS 1
+#define TPAMD_CHAIN_GUESS 0
 #endif
 constexpr int kTileSamples = TPAMD_TILE_SAMPLES;   // largest tile (the engine pads the records by one)
 // Samples per tile of the D-joint sweep: wide records (D > 8: 30 doubles at D = 14) take 16-sample
