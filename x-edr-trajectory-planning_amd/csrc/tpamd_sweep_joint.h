@@ -200,9 +200,21 @@ __device__ __forceinline__ long long tpamd_stamp() {
 #endif
 #define TPAMD_CNT(slot) diag[slot] += 1
 #define TPAMD_ADD(slot, v) diag[slot] += (v)
+// the coarse stamps (phases of the kernel: a dozen per path); -DTPAMD_DIAG_LIGHT keeps only these, so
+// that the build runs like the product (the fine stamps serialise the hot loops)
+#define TPAMD_T0C(var) const long long var = tpamd_stamp()
+#define TPAMD_ACCC(slot, var) diag[slot] += tpamd_stamp() - (var)
+#ifdef TPAMD_DIAG_LIGHT
+#undef TPAMD_T0
+#undef TPAMD_ACC
+#define TPAMD_T0(var)
+#define TPAMD_ACC(slot, var)
+#endif
 #else
 #define TPAMD_T0(var)
 #define TPAMD_ACC(slot, var)
+#define TPAMD_T0C(var)
+#define TPAMD_ACCC(slot, var)
 #define TPAMD_CNT(slot)
 #define TPAMD_ADD(slot, v)
 #endif
@@ -217,6 +229,15 @@ __device__ __forceinline__ long long tpamd_stamp() {
 // count, got 0.5 % (pipelined) to 1.8 % (one kernel at a time) slower. Off; kept for the record.
 #ifndef TPAMD_CHAIN_GUESS
 #define TPAMD_CHAIN_GUESS 0
+#endif
+// A speculative block whose first failing step fails only because its (verified) new sd2 lies above
+// the limit curve finishes that step itself (leave_on_curve) instead of handing it to a scalar step.
+#ifndef TPAMD_CURVE_EXIT
+#define TPAMD_CURVE_EXIT 1
+#endif
+// Alternate the roles of a workgroup's two waves with the SIMD placement (see k_sweep_joint).
+#ifndef TPAMD_ROLE_SWAP
+#define TPAMD_ROLE_SWAP 1
 #endif
 constexpr int kTileSamples = TPAMD_TILE_SAMPLES;   // largest tile (the engine pads the records by one)
 // Samples per tile of the D-joint sweep: wide records (D > 8: 30 doubles at D = 14) take 16-sample
@@ -876,11 +897,16 @@ struct JointSweep {
   // redone by the scalar step. Returns the number of steps taken (0..16).
   // next_win: where a block ended short of K steps because the active constraint changed, the lane
   // (find_sdd layout) of the candidate that took over at the first unverified step, else -1.
+  // curve: set when the first step that did not stand failed for ONE reason only: its FindSdd result
+  // is verified (it is what the scalar step would compute) but the new sd2 exceeds the limit curve
+  // (.cc:806 / :896). c.m_i / c.m_n / c.t_n then hold that step's boundary data and the caller goes
+  // on with leave_on_curve instead of a scalar step that would find the same sdd again.
   template <bool FWD>
-  __device__ __forceinline__ int follow_chain(Carry &c, Prefetch &pf, int &next_win) {
+  __device__ __forceinline__ int follow_chain(Carry &c, Prefetch &pf, int &next_win, bool &curve) {
     constexpr int dir = FWD ? 1 : -1;
     constexpr int K = L::kChain;
     next_win = -1;
+    curve = false;
     const int wl = c.win;
     const int r = (wl / L::PARTS) >> 1;                  // row of the speculated candidate
     const double alim = readlane_f64(lim, wl);           // its bound
@@ -955,10 +981,11 @@ struct JointSweep {
     const int t_j = __double2loint(mt_j.y), t_n = __double2loint(mt_n.y);
     const double m_j = mt_j.x, m_n = mt_n.x;
     const bool riding = is_tiny(my_cur - m_j) & ((t_j & kBndTrajectory) != 0) & ((t_n & kBndTrajectory) != 0);
-    const bool special = riding | (!isnan(nxt) & (nxt < my_new)) | (my_new > m_n) | (my_new < 0) |
-                         isnan(my_new);
-    // a step stands if none of its lanes objects: one ballot, folded over the lanes of a step
-    unsigned long long fm = __ballot(bad | !in_loop | !bits_equal | special);
+    const bool special = riding | (!isnan(nxt) & (nxt < my_new)) | (my_new < 0) | isnan(my_new);
+    // a step stands if none of its lanes objects: two ballots (the limit curve apart, see `curve`),
+    // folded over the lanes of a step
+    const unsigned long long fo = __ballot(bad | !in_loop | !bits_equal | special);
+    unsigned long long fm = fo | __ballot(my_new > m_n);
     if (G >= 2) fm |= fm >> 1;
     if (G >= 4) fm |= fm >> 2;
     const unsigned long long miss = fm & L::kPart0;     // bit 4k: step k failed
@@ -979,12 +1006,22 @@ struct JointSweep {
       // Why did step Lc fail? If only because another constraint became active (no special case of
       // the scalar step, the chain value itself was right), its lanes know which one: the next
       // block can start from it without a scalar FindSdd step in between.
-      const unsigned long long other = __ballot(!in_loop | !bits_equal | special);
+      const unsigned long long other = __ballot(!in_loop | !bits_equal | special | (my_new > m_n));
       const unsigned long long hints = __ballot(guess >= 0);
       const unsigned long long lanes = ((1ull << G) - 1ull) << (G * Lc);
       if ((other & lanes) == 0ull && (hints & lanes) != 0ull) {
         const int src = __ffsll((long long)(hints & lanes)) - 1;
         next_win = __builtin_amdgcn_readlane(guess, src) * L::PARTS;
+      }
+    }
+    if (TPAMD_CURVE_EXIT && Lc < K) {
+      // (my_new > m_n is then the reason: a step fails for one of the terms of `fm`)
+      const unsigned long long lanes = ((1ull << G) - 1ull) << (G * Lc);
+      if ((fo & lanes) == 0ull) {
+        curve = true;
+        c.m_i = readlane_f64(m_j, G * Lc);
+        c.m_n = readlane_f64(m_n, G * Lc);
+        c.t_n = __builtin_amdgcn_readlane(t_n, G * Lc);
       }
     }
     if (Lc == 0) return 0;
@@ -996,6 +1033,46 @@ struct JointSweep {
     c.idx = j0 + dir * Lc;
     c.cur = readlane_f64(my_new, G * (Lc - 1));
     return Lc;
+  }
+
+  // The rest of a step whose FindSdd result a chain block verified and whose new sd2 lies above the
+  // limit curve (extremal_step from `if (sd2tmp > m_n)` on, .cc:806-855 / :896-950; neither the
+  // boundary-following case nor the intersection test applied). c.idx / c.cur: the step's sample and
+  // sd2; c.m_i, c.m_n, c.t_n as follow_chain left them.
+  template <bool FWD>
+  __device__ __forceinline__ int leave_on_curve(Carry &c, int idx_start) {
+    constexpr int dir = FWD ? 1 : -1;
+    const int idx = c.idx, nidx = idx + dir;
+    const bool more = FWD ? (nidx < N - 2) : (nidx > 1);
+    const double cur = c.cur, m_n = c.m_n;
+    const double sdd_bound = FWD ? 0.5 * (m_n - cur) / ds : 0.5 * (cur - m_n) / ds;
+    const bool deriv_invalid = !derivs_valid(idx, sdd_bound, FWD ? c.m_i : cur);
+    const bool type_invalid = c.t_n & (FWD ? kBndSink : kBndSource);
+    const bool stop = FWD ? (type_invalid || deriv_invalid)
+                          : ((type_invalid || deriv_invalid) && !(idx_start != (N - 1)));
+    if (stop) {
+      end_idx = idx;
+      return idx;
+    }
+    double sd2tmp = m_n, sddtmp = sdd_bound;
+    c.win = -1;
+    if (sd2tmp < 0) {
+      sd2tmp = 0.0;
+      if (FWD) {
+        if (idx <= 1) sddtmp = 0.0; else sddtmp = -sd2[idx - 1] / ds;
+      } else {
+        if (idx < N - 1) sddtmp = sd2[idx + 1] / ds; else sddtmp = 0.0;
+      }
+    }
+    put_sd2(nidx, sd2tmp);
+    put_sdd(idx, sddtmp);
+    if (!more) {
+      end_idx = nidx;
+      return FWD ? N - 1 : 0;
+    }
+    c.idx = nidx;
+    c.cur = sd2tmp;
+    return kContinue;
   }
 
   // (Re)start the carried state at sample idx: tiles, rows, neighbours.
@@ -1081,19 +1158,27 @@ struct JointSweep {
 #define TPAMD_TRY_CHAIN()                                                                    \
   if (c.win >= 0 && (trust || c.win == last_win)) {                                          \
     int total = 0, run, next_win;                                                            \
-    bool again;                                                                              \
+    bool again, curve;                                                                       \
     do {                                                                                     \
-      { TPAMD_T0(tc_); run = uniform_i32(follow_chain<FWD>(c, pf, next_win)); TPAMD_ACC(4, tc_); } \
+      { TPAMD_T0(tc_); run = uniform_i32(follow_chain<FWD>(c, pf, next_win, curve)); TPAMD_ACC(4, tc_); } \
       TPAMD_CNT(6);                                                                          \
       total += run;                                                                          \
       again = run == L::kChain;                                                              \
       /* the active constraint changed inside the block: go on with the one that took over */ \
-      if (run > 0 && run < L::kChain && next_win >= 0) { c.win = uniform_i32(next_win); again = true; TPAMD_CNT(30); } \
+      if (run > 0 && run < L::kChain && next_win >= 0) { c.win = uniform_i32(next_win); again = true; } \
     } while (again && (FWD ? (c.idx < N - 2) : (c.idx > 1)));                                \
     trust = total > 0;                                                                       \
     last_win = -1;                                                                           \
+    TPAMD_ADD(14, total);                                                                    \
+    if (curve) {                                                                             \
+      /* the block verified this step's FindSdd and found the new sd2 above the limit curve */ \
+      TPAMD_CNT(30);                                                                         \
+      trust = true;                                                                          \
+      const int rc = leave_on_curve<FWD>(c, idx_start);                                      \
+      if (rc != kContinue) return rc;                                                        \
+      total = 1;   /* (the extremal moved: re-initialise below, as after any block) */       \
+    }                                                                                        \
     if (total > 0) {                                                                         \
-      TPAMD_ADD(14, total);                                                                  \
       if (FWD ? !(c.idx < N - 2) : !(c.idx > 1)) {                                           \
         end_idx = c.idx;                                                                     \
         return FWD ? N - 1 : 0;                                                              \
@@ -1315,7 +1400,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
                                                          int N, int stride, int tid, uint8_t *at_l,
                                                          uint8_t *ff_l, char *scratch, uint8_t *typel,
                                                          bool keep, long long *diag) {
-  TPAMD_T0(tp0);
+  TPAMD_T0C(tp0);
   const size_t pb = (size_t)b * stride;
   const int lane = tid & 63, w = tid >> 6;
   const double *m0 = ws.m0 + pb, *z0 = ws.z0 + pb, *X0 = ws.X0 + pb, *Y0 = ws.Y0 + pb;
@@ -1345,7 +1430,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
     iso_l[i] = (uint8_t)((i >= 1) & (i <= N - 2) & (a0 == 0) & (a1 != 0) & (a2 == 0));
   }
   __syncthreads();
-  TPAMD_ACC(19, tp0);
+  TPAMD_ACCC(19, tp0);
 
 #ifndef TPAMD_BOUNDARY_FAST
 #define TPAMD_BOUNDARY_FAST 1
@@ -1420,7 +1505,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
       P.template flush<false>(diag);
       __threadfence_block();
       __syncthreads();
-      TPAMD_ACC(20, tp0);
+      TPAMD_ACCC(20, tp0);
     }
     // pass 2, second half for one sample, everything from memory (k_boundary_detect)
     auto detect_one = [&](int k) {
@@ -1508,7 +1593,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
     }
     __threadfence_block();
     __syncthreads();
-    TPAMD_ACC(21, tp0);
+    TPAMD_ACCC(21, tp0);
 
     // passes 3 and 4 for one sample, everything from memory (k_boundary_final)
     auto final_one = [&](int j, double &m, double &X, double &Y, double &m_next) -> bool {
@@ -1582,7 +1667,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
     P.template flush<true>(diag);
     __threadfence_block();
     __syncthreads();
-    TPAMD_ACC(22, tp0);
+    TPAMD_ACCC(22, tp0);
     };
     if (nseg == 1) fast_form(std::true_type{});
     else fast_form(std::false_type{});
@@ -1599,7 +1684,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
   P.template flush<false>(diag);
   __threadfence_block();
   __syncthreads();
-  TPAMD_ACC(20, tp0);
+  TPAMD_ACCC(20, tp0);
 
   // pass 2, second half (.cc:1396-1431): skipped maxima -> deferred fixes
   for (int k0 = tid; k0 < N; k0 += 128 * U) {
@@ -1661,7 +1746,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
   }
   __threadfence_block();
   __syncthreads();
-  TPAMD_ACC(21, tp0);
+  TPAMD_ACCC(21, tp0);
 
   // passes 3 and 4 (.cc:1432-1484): final boundary value, its sdd range, classification.
   // final value of element j+1 (the last writer among the deferred fixes, see k_boundary_final)
@@ -1724,7 +1809,7 @@ __device__ __forceinline__ void boundary_passes_for_path(const JointSource &src,
   P.template flush<true>(diag);
   __threadfence_block();
   __syncthreads();
-  TPAMD_ACC(22, tp0);
+  TPAMD_ACCC(22, tp0);
 }
 
 // Dynamic LDS of one path (bytes):
@@ -1785,9 +1870,27 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   typedef SweepLds<D, E> LL;
   const int b = uniform_i32(path_of_block(ws, blockIdx.x));
   const int lane = threadIdx.x & 63;
-  const int w = uniform_i32((int)(threadIdx.x >> 6));
-  const int tid = threadIdx.x;
   const int N = path_samples(ws, b, stride);   // samples of this path; arrays use `stride`
+  // Which of the two waves is "wave 0" (backward extremals, time sum) and which "wave 1" (forward
+  // extremals, the critical path of a switching-point loop) is a labelling the code is free to
+  // choose. The hardware deals the waves of consecutive workgroups round-robin over the four SIMDs
+  // of a CU, so with a fixed labelling the two forward waves of the workgroups that share a SIMD
+  // pair land on ONE SIMD and their dependent chains slow each other while the SIMD next door
+  // hosts two waves with slack. The labelling therefore alternates with the (SIMD + wave slot)
+  // parity of the first wave: every SIMD then hosts one wave of each kind.
+  int w_phys = (int)(threadIdx.x >> 6);
+  if (TPAMD_ROLE_SWAP) {
+    const int Nc = min(max(N, 0), stride);     // (a path with a bad sample count leaves right below)
+    int *word = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(lds + SweepLds<D, E>::n2(Nc) + SweepLds<D, E>::kRingDoubles) +
+                                        SweepLds<D, E>::type_bytes(Nc)) + 15;  // xchg[15], used for nothing else
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (threadIdx.x == 0) *word = (int)(((hw >> 4) & 3u) + (hw & 15u)) & 1;
+    __syncthreads();
+    w_phys ^= *word;
+  }
+  const int w = uniform_i32(w_phys);
+  const int tid = w * 64 + lane;
   const size_t pb = (size_t)b * stride;
   const uint32_t bits = ws.err_bits[b];
   if (bits & kErrSkip) return;          // not part of this solve: outputs stay as they are
@@ -1928,7 +2031,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   int iforw_lo = 0, iback_hi = N - 1, iback_lo, iforw_hi, icrit, icrit_lo, icrit_hi;
   typename JS::Prefetch pf;
   pf.tag = -1;
-  TPAMD_T0(t_all);
+  TPAMD_T0C(t_all);
   // First pair (time_optimal_path_timing.cc:325-326): the backward extremal from N-1, then the
   // forward one from 0, which may run into it. They are run SIDE BY SIDE first: if they end more
   // than 70 samples apart neither has seen anything of the other -- an extremal reads sd2 at
@@ -1998,7 +2101,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   }
   iback_lo = uniform_i32(xchg[0]);
   iforw_hi = uniform_i32(xchg[1]);
-  TPAMD_ACC(9, t_all);   // first pair (sequential)
+  TPAMD_ACCC(9, t_all);   // first pair (sequential)
   icrit_hi = iback_lo;
   if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
     if (w == 0) S.put_sd2(icrit_hi, qnan());
@@ -2017,7 +2120,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
       TPAMD_T0(t0);
       icrit = uniform_i32(S.next_critical_point(icrit_lo, icrit_hi, zlast));
       TPAMD_ACC(2, t0);
-#ifdef TPAMD_DIAG
+#if defined(TPAMD_DIAG) && !defined(TPAMD_DIAG_LIGHT)
       {
         TPAMD_T0(tl_);
         if (icrit != S.next_critical_point_literal(icrit_lo, icrit_hi)) TPAMD_CNT(7);
@@ -2045,7 +2148,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     iforw_lo = icrit;
     __syncthreads();                 // A: the marks are visible to the forward wave
     {
-      TPAMD_T0(t0);
+      TPAMD_T0C(t0);
       if (w == 0) {
         const int r = S.template add_extremal<false>(iback_hi, pf, /*pair_signal=*/true);   // B inside
         if (lane == 0) xchg[0] = r;
@@ -2066,20 +2169,20 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
           *reinterpret_cast<volatile int *>(xchg + 6) = loop + 1;
         }
       }
-      TPAMD_ACC(0, t0);
+      TPAMD_ACCC(0, t0);
     }
     {
-      TPAMD_T0(t0);
+      TPAMD_T0C(t0);
       __threadfence_block();
       __syncthreads();               // C
-      TPAMD_ACC(1, t0);              // time spent waiting for the partner's extremal
+      TPAMD_ACCC(1, t0);              // time spent waiting for the partner's extremal
     }
     iback_lo = uniform_i32(xchg[0]);
     iforw_hi = uniform_i32(xchg[1]);
     if (iback_lo > icrit_lo) { status = 7; break; }
     icrit_lo = iforw_hi;
   }
-  TPAMD_ACC(5, t_all);
+  TPAMD_ACCC(5, t_all);
   if (lane == 0) {
     if (w == 0) { xchg[4] = emitted_hi; xchg[5] = upper_lo; }
     else xchg[3] = S.end_idx;          // where the last forward extremal ended
@@ -2092,7 +2195,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   // Tail (time_optimal_path_timing.cc:398-477), shared by the two waves. `status` is uniform
   // over the workgroup (both waves computed it from the same exchanged values).
   // ---------------------------------------------------------------------------------------
-  TPAMD_T0(t_tail);
+  TPAMD_T0C(t_tail);
   const double ds = S.ds;
   double *sdd = S.sdd_g;
   {
@@ -2348,8 +2451,8 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     study[2 * b + 1] = t;
   }
 #endif
-  TPAMD_ACC(3, t_tail);
-  TPAMD_ACC(15, t_all);
+  TPAMD_ACCC(3, t_tail);
+  TPAMD_ACCC(15, t_all);
 #ifdef TPAMD_DIAG
   if (lane == 0 && ws.diag)
     for (int k = 0; k < 32; k++) ws.diag[(size_t)b * 64 + 32 * w + k] = S.diag[k];
