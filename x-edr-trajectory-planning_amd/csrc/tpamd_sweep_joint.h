@@ -237,7 +237,12 @@ __device__ __forceinline__ long long tpamd_stamp() {
 #endif
 // Alternate the roles of a workgroup's two waves with the SIMD placement (see k_sweep_joint).
 #ifndef TPAMD_ROLE_SWAP
-#define TPAMD_ROLE_SWAP 1
+#define TPAMD_ROLE_SWAP 0    // measured: no difference (0.508 ms per step either way)
+#endif
+// The forward wave finds a loop's critical point and its limit-curve values before the previous
+// loop's closing barrier (see k_sweep_joint).
+#ifndef TPAMD_CRIT_AHEAD
+#define TPAMD_CRIT_AHEAD 1
 #endif
 constexpr int kTileSamples = TPAMD_TILE_SAMPLES;   // largest tile (the engine pads the records by one)
 // Samples per tile of the D-joint sweep: wide records (D > 8: 30 doubles at D = 14) take 16-sample
@@ -2112,6 +2117,101 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   const int zlast = uniform_i32(S.last_flagged_below(icrit_hi));   // icrit_hi is final from here on
   const double *m_g = ws.m + pb;
   if (max_loops <= 0) max_loops = max(100, 10 * N);   // path_timing_trajectory.cc:398-400
+#if TPAMD_CRIT_AHEAD
+  // The switching-point loop, .cc:329-397. What a loop needs before its two extremals can start --
+  // the next critical point (a scan of the type bytes above the forward extremal's end) and the
+  // limit-curve values next to it (two global loads) -- depends on nothing the backward wave
+  // produces, so the forward wave finds them right after its own extremal, while the backward wave
+  // finishes its qd/qdd trip, and posts them in LDS before the loop's closing barrier: a loop is two
+  // workgroup barriers (A, C) with nothing but the marks between C and A.
+  double *crit_m = reinterpret_cast<double *>(xchg + 10);     // [0] sd2_max[icrit], [1] sd2_max[icrit - 1]
+  auto post_next_critical_point = [&](int lo) {               // forward wave only
+    TPAMD_T0(t0);
+    int ic = uniform_i32(S.next_critical_point(lo, icrit_hi, zlast));
+    TPAMD_ACC(2, t0);
+#if defined(TPAMD_DIAG) && !defined(TPAMD_DIAG_LIGHT)
+    {
+      TPAMD_T0(tl_);
+      if (ic != S.next_critical_point_literal(lo, icrit_hi)) TPAMD_CNT(7);
+      TPAMD_ACC(18, tl_);
+    }
+#endif
+    if (ic < 0 || ic >= N) ic = (int)(0.5 * (lo + icrit_hi));
+    const double mc = m_g[min(max(ic, 0), N - 1)], mp = m_g[min(max(ic - 1, 0), N - 1)];
+    if (ic >= 1) {
+      // the tile the next forward extremal starts in: its loads fly during the barrier
+      const int ts = ic / JS::kTile;
+      const int tag = (ts & 1) ? S.tag1 : S.tag0;
+      if (tag != ts && pf.tag != ts) S.issue_tile_loads(ts, pf);
+    }
+    if (lane == 0) {
+      xchg[9] = ic;
+      crit_m[0] = mc;
+      crit_m[1] = mp;
+    }
+  };
+  __syncthreads();     // the NaN mark above is visible (the literal walk of the diagnostic build reads sd2)
+  if (w == 1 && iforw_hi < icrit_hi) post_next_critical_point(icrit_lo);
+  __threadfence_block();
+  __syncthreads();
+  for (int loop = 0; loop < max_loops; loop++) {
+    if (iforw_hi >= icrit_hi) break;
+    TPAMD_CNT(11);
+    icrit = uniform_i32(xchg[9]);
+    const double m_c = uniform_f64(crit_m[0]), m_p = uniform_f64(crit_m[1]);
+    if (w == 0 && icrit >= 1) {
+      const int ts = (icrit - 1) / JS::kTile;
+      const int tag = (ts & 1) ? S.tag1 : S.tag0;
+      if (tag != ts && pf.tag != ts) S.issue_tile_loads(ts, pf);
+    }
+    // (both waves are past their extremals: nobody reads sd2 while the marks are written)
+    if (icrit > 0 && icrit < N - 1 && w == 0) S.put_sd2(icrit, m_c);
+    if (icrit < 1) { status = 10; break; }
+    if (m_p <= m_c) {
+      iback_hi = icrit - 1;
+      if (w == 0) S.put_sd2(icrit - 1, m_p);
+    } else {
+      iback_hi = icrit;
+    }
+    iforw_lo = icrit;
+    __syncthreads();                 // A: the marks are visible to the forward wave
+    {
+      TPAMD_T0C(t0);
+      if (w == 0) {
+        const int r = S.template add_extremal<false>(iback_hi, pf, /*pair_signal=*/true);   // B inside
+        if (lane == 0) xchg[0] = r;
+        // The forward extremal of this loop works on samples >= icrit and usually takes
+        // longer: write qd/qdd for everything below icrit that is new or was changed by this
+        // backward extremal (it ended at end_idx) while waiting for it.
+        // -- but only until that one is done (xchg[6] then holds this loop's number): the
+        // rest waits for the next loop or the tail.
+        TPAMD_T0(te);
+        if (TPAMD_EMIT_IN_LOOP)
+          emitted_hi = uniform_i32(S.emit_range(max(min(S.end_idx - 1, emitted_hi), 0), icrit - 1,
+                                                0, 1, xchg + 6, loop + 1));
+        TPAMD_ACC(12, te);
+      } else {
+        const int r = S.template add_extremal<true>(iforw_lo, pf, false, /*wait_pair=*/true);   // B inside
+        if (lane == 0) {
+          xchg[1] = r;
+          *reinterpret_cast<volatile int *>(xchg + 6) = loop + 1;
+        }
+        if (r < icrit_hi) post_next_critical_point(r);      // for the next loop, if there is one
+      }
+      TPAMD_ACCC(0, t0);
+    }
+    {
+      TPAMD_T0C(t0);
+      __threadfence_block();
+      __syncthreads();               // C
+      TPAMD_ACCC(1, t0);             // time spent waiting for the partner's extremal
+    }
+    iback_lo = uniform_i32(xchg[0]);
+    iforw_hi = uniform_i32(xchg[1]);
+    if (iback_lo > icrit_lo) { status = 7; break; }
+    icrit_lo = iforw_hi;
+  }
+#else
   for (int loop = 0; loop < max_loops; loop++) {
     if (iforw_hi >= icrit_hi) break;
     TPAMD_CNT(11);
@@ -2182,6 +2282,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     if (iback_lo > icrit_lo) { status = 7; break; }
     icrit_lo = iforw_hi;
   }
+#endif
   TPAMD_ACCC(5, t_all);
   if (lane == 0) {
     if (w == 0) { xchg[4] = emitted_hi; xchg[5] = upper_lo; }
