@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+for rep in 1 2; do for lib in libtpamd.so libtpamd_prio3.so libtpamd_prio3_t16.so libtpamd_t16.so; do
+TPAMD_LIBRARY=$PWD/x-edr-trajectory-planning_amd/csrc/$lib timeout -k 10 300 python bench.py --steps 300 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('$lib piped', d['value'], d['ms_per_step'], d['config']['solved_paths'], {k:v['ms'] for k,v in d['roofline']['kernels'].items()})"
+done; done

@@ -1918,6 +1918,9 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     study[2 * b] = t | ((unsigned long long)(xcc & 15u) << 60);
   }
 #endif
+#ifdef TPAMD_SWEEP_PRIO
+  __builtin_amdgcn_s_setprio(TPAMD_SWEEP_PRIO);   // A/B: issue priority of the sweep's waves over a co-resident kernel
+#endif
   JS S;
   S.N = N; S.lane = lane;
   S.ds = ws.ds[b];
@@ -2054,6 +2057,12 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 #ifndef TPAMD_EMIT_IN_LOOP
 #define TPAMD_EMIT_IN_LOOP 1
 #endif
+// Wave 0 also writes qd/qdd of the region the first backward extremal set while a loop leaves it waiting.
+// Measured: the tail gets 7 k cycles shorter and the loops as much longer (the forward wave waits for the
+// extra trips to end): 0.503 against 0.501 ms per step. Off.
+#ifndef TPAMD_EMIT_UPPER
+#define TPAMD_EMIT_UPPER 0
+#endif
   bool first_pair_in_order = !TPAMD_FIRST_PAIR_CONCURRENT;
   if (TPAMD_FIRST_PAIR_CONCURRENT) {
     if (w == 0) {
@@ -2106,6 +2115,11 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   }
   iback_lo = uniform_i32(xchg[0]);
   iforw_hi = uniform_i32(xchg[1]);
+  // The region the first backward extremal set (short of its lower end, see above) is final unless the
+  // last forward extremal runs into it (the tail redoes what that one rewrites): where the first pair
+  // ran side by side, wave 0 writes its qd/qdd from the top down whenever a loop leaves it waiting with
+  // nothing else to write (upper_lo moves down to upper_floor).
+  const int upper_floor = first_pair_in_order ? upper_lo : min(uniform_i32(xchg[7]) + 3, N);
   TPAMD_ACCC(9, t_all);   // first pair (sequential)
   icrit_hi = iback_lo;
   if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
@@ -2186,9 +2200,16 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
         // -- but only until that one is done (xchg[6] then holds this loop's number): the
         // rest waits for the next loop or the tail.
         TPAMD_T0(te);
-        if (TPAMD_EMIT_IN_LOOP)
+        if (TPAMD_EMIT_IN_LOOP) {
           emitted_hi = uniform_i32(S.emit_range(max(min(S.end_idx - 1, emitted_hi), 0), icrit - 1,
                                                 0, 1, xchg + 6, loop + 1));
+          while (TPAMD_EMIT_UPPER && upper_lo > upper_floor &&
+                 *reinterpret_cast<const volatile int *>(xchg + 6) != loop + 1) {
+            const int lo = max(upper_lo - 64, upper_floor);
+            S.emit_range(lo, upper_lo - 1, 0, 1);      // one trip
+            upper_lo = lo;
+          }
+        }
         TPAMD_ACC(12, te);
       } else {
         const int r = S.template add_extremal<true>(iforw_lo, pf, false, /*wait_pair=*/true);   // B inside
@@ -2258,9 +2279,16 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
         // -- but only until that one is done (xchg[6] then holds this loop's number): the
         // rest waits for the next loop or the tail.
         TPAMD_T0(te);
-        if (TPAMD_EMIT_IN_LOOP)
+        if (TPAMD_EMIT_IN_LOOP) {
           emitted_hi = uniform_i32(S.emit_range(max(min(S.end_idx - 1, emitted_hi), 0), icrit - 1,
                                                 0, 1, xchg + 6, loop + 1));
+          while (TPAMD_EMIT_UPPER && upper_lo > upper_floor &&
+                 *reinterpret_cast<const volatile int *>(xchg + 6) != loop + 1) {
+            const int lo = max(upper_lo - 64, upper_floor);
+            S.emit_range(lo, upper_lo - 1, 0, 1);      // one trip
+            upper_lo = lo;
+          }
+        }
         TPAMD_ACC(12, te);
       } else {
         const int r = S.template add_extremal<true>(iforw_lo, pf, false, /*wait_pair=*/true);   // B inside
