@@ -235,15 +235,6 @@ __device__ __forceinline__ long long tpamd_stamp() {
 #ifndef TPAMD_CURVE_EXIT
 #define TPAMD_CURVE_EXIT 1
 #endif
-// Alternate the roles of a workgroup's two waves with the SIMD placement (see k_sweep_joint).
-#ifndef TPAMD_ROLE_SWAP
-#define TPAMD_ROLE_SWAP 0    // measured: no difference (0.508 ms per step either way)
-#endif
-// The forward wave finds a loop's critical point and its limit-curve values before the previous
-// loop's closing barrier (see k_sweep_joint).
-#ifndef TPAMD_CRIT_AHEAD
-#define TPAMD_CRIT_AHEAD 1
-#endif
 constexpr int kTileSamples = TPAMD_TILE_SAMPLES;   // largest tile (the engine pads the records by one)
 // Samples per tile of the D-joint sweep: wide records (D > 8: 30 doubles at D = 14) take 16-sample
 // tiles, which halves the prefetch registers and the rings (the 14-joint kernel spilled 288 bytes
@@ -1876,26 +1867,8 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   const int b = uniform_i32(path_of_block(ws, blockIdx.x));
   const int lane = threadIdx.x & 63;
   const int N = path_samples(ws, b, stride);   // samples of this path; arrays use `stride`
-  // Which of the two waves is "wave 0" (backward extremals, time sum) and which "wave 1" (forward
-  // extremals, the critical path of a switching-point loop) is a labelling the code is free to
-  // choose. The hardware deals the waves of consecutive workgroups round-robin over the four SIMDs
-  // of a CU, so with a fixed labelling the two forward waves of the workgroups that share a SIMD
-  // pair land on ONE SIMD and their dependent chains slow each other while the SIMD next door
-  // hosts two waves with slack. The labelling therefore alternates with the (SIMD + wave slot)
-  // parity of the first wave: every SIMD then hosts one wave of each kind.
-  int w_phys = (int)(threadIdx.x >> 6);
-  if (TPAMD_ROLE_SWAP) {
-    const int Nc = min(max(N, 0), stride);     // (a path with a bad sample count leaves right below)
-    int *word = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(lds + SweepLds<D, E>::n2(Nc) + SweepLds<D, E>::kRingDoubles) +
-                                        SweepLds<D, E>::type_bytes(Nc)) + 15;  // xchg[15], used for nothing else
-    unsigned hw;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    if (threadIdx.x == 0) *word = (int)(((hw >> 4) & 3u) + (hw & 15u)) & 1;
-    __syncthreads();
-    w_phys ^= *word;
-  }
-  const int w = uniform_i32(w_phys);
-  const int tid = w * 64 + lane;
+  const int w = uniform_i32((int)(threadIdx.x >> 6));
+  const int tid = threadIdx.x;
   const size_t pb = (size_t)b * stride;
   const uint32_t bits = ws.err_bits[b];
   if (bits & kErrSkip) return;          // not part of this solve: outputs stay as they are
@@ -1917,9 +1890,6 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     study[2 * b] = t | ((unsigned long long)(xcc & 15u) << 60);
   }
-#endif
-#ifdef TPAMD_SWEEP_PRIO
-  __builtin_amdgcn_s_setprio(TPAMD_SWEEP_PRIO);   // A/B: issue priority of the sweep's waves over a co-resident kernel
 #endif
   JS S;
   S.N = N; S.lane = lane;
@@ -2057,12 +2027,6 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
 #ifndef TPAMD_EMIT_IN_LOOP
 #define TPAMD_EMIT_IN_LOOP 1
 #endif
-// Wave 0 also writes qd/qdd of the region the first backward extremal set while a loop leaves it waiting.
-// Measured: the tail gets 7 k cycles shorter and the loops as much longer (the forward wave waits for the
-// extra trips to end): 0.503 against 0.501 ms per step. Off.
-#ifndef TPAMD_EMIT_UPPER
-#define TPAMD_EMIT_UPPER 0
-#endif
   bool first_pair_in_order = !TPAMD_FIRST_PAIR_CONCURRENT;
   if (TPAMD_FIRST_PAIR_CONCURRENT) {
     if (w == 0) {
@@ -2115,11 +2079,6 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   }
   iback_lo = uniform_i32(xchg[0]);
   iforw_hi = uniform_i32(xchg[1]);
-  // The region the first backward extremal set (short of its lower end, see above) is final unless the
-  // last forward extremal runs into it (the tail redoes what that one rewrites): where the first pair
-  // ran side by side, wave 0 writes its qd/qdd from the top down whenever a loop leaves it waiting with
-  // nothing else to write (upper_lo moves down to upper_floor).
-  const int upper_floor = first_pair_in_order ? upper_lo : min(uniform_i32(xchg[7]) + 3, N);
   TPAMD_ACCC(9, t_all);   // first pair (sequential)
   icrit_hi = iback_lo;
   if ((iforw_hi < icrit_hi) && ((icrit_hi < N - 2) && (icrit_hi >= 2))) {
@@ -2131,7 +2090,6 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   const int zlast = uniform_i32(S.last_flagged_below(icrit_hi));   // icrit_hi is final from here on
   const double *m_g = ws.m + pb;
   if (max_loops <= 0) max_loops = max(100, 10 * N);   // path_timing_trajectory.cc:398-400
-#if TPAMD_CRIT_AHEAD
   // The switching-point loop, .cc:329-397. What a loop needs before its two extremals can start --
   // the next critical point (a scan of the type bytes above the forward extremal's end) and the
   // limit-curve values next to it (two global loads) -- depends on nothing the backward wave
@@ -2203,12 +2161,6 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
         if (TPAMD_EMIT_IN_LOOP) {
           emitted_hi = uniform_i32(S.emit_range(max(min(S.end_idx - 1, emitted_hi), 0), icrit - 1,
                                                 0, 1, xchg + 6, loop + 1));
-          while (TPAMD_EMIT_UPPER && upper_lo > upper_floor &&
-                 *reinterpret_cast<const volatile int *>(xchg + 6) != loop + 1) {
-            const int lo = max(upper_lo - 64, upper_floor);
-            S.emit_range(lo, upper_lo - 1, 0, 1);      // one trip
-            upper_lo = lo;
-          }
         }
         TPAMD_ACC(12, te);
       } else {
@@ -2232,85 +2184,6 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
     if (iback_lo > icrit_lo) { status = 7; break; }
     icrit_lo = iforw_hi;
   }
-#else
-  for (int loop = 0; loop < max_loops; loop++) {
-    if (iforw_hi >= icrit_hi) break;
-    TPAMD_CNT(11);
-    __syncthreads();   // sd2 writes of the other wave / the NaN mark are visible
-    {
-      TPAMD_T0(t0);
-      icrit = uniform_i32(S.next_critical_point(icrit_lo, icrit_hi, zlast));
-      TPAMD_ACC(2, t0);
-#if defined(TPAMD_DIAG) && !defined(TPAMD_DIAG_LIGHT)
-      {
-        TPAMD_T0(tl_);
-        if (icrit != S.next_critical_point_literal(icrit_lo, icrit_hi)) TPAMD_CNT(7);
-        TPAMD_ACC(18, tl_);
-      }
-#endif
-    }
-    if (icrit < 0 || icrit >= N) icrit = (int)(0.5 * (icrit_lo + icrit_hi));
-    if (icrit >= 1) {
-      // the tile this wave's extremal starts in: its loads fly together with the loads of
-      // the boundary values below instead of after them
-      const int ts = ((w == 1) ? icrit : icrit - 1) / JS::kTile;
-      const int tag = (ts & 1) ? S.tag1 : S.tag0;
-      if (tag != ts && pf.tag != ts) S.issue_tile_loads(ts, pf);
-    }
-    __syncthreads();   // both waves finished reading sd2 before the marks below
-    if (icrit > 0 && icrit < N - 1 && w == 0) S.put_sd2(icrit, m_g[icrit]);
-    if (icrit < 1) { status = 10; break; }
-    if (m_g[icrit - 1] <= m_g[icrit]) {
-      iback_hi = icrit - 1;
-      if (w == 0) S.put_sd2(icrit - 1, m_g[icrit - 1]);
-    } else {
-      iback_hi = icrit;
-    }
-    iforw_lo = icrit;
-    __syncthreads();                 // A: the marks are visible to the forward wave
-    {
-      TPAMD_T0C(t0);
-      if (w == 0) {
-        const int r = S.template add_extremal<false>(iback_hi, pf, /*pair_signal=*/true);   // B inside
-        if (lane == 0) xchg[0] = r;
-        // The forward extremal of this loop works on samples >= icrit and usually takes
-        // longer: write qd/qdd for everything below icrit that is new or was changed by this
-        // backward extremal (it ended at end_idx) while waiting for it.
-        // -- but only until that one is done (xchg[6] then holds this loop's number): the
-        // rest waits for the next loop or the tail.
-        TPAMD_T0(te);
-        if (TPAMD_EMIT_IN_LOOP) {
-          emitted_hi = uniform_i32(S.emit_range(max(min(S.end_idx - 1, emitted_hi), 0), icrit - 1,
-                                                0, 1, xchg + 6, loop + 1));
-          while (TPAMD_EMIT_UPPER && upper_lo > upper_floor &&
-                 *reinterpret_cast<const volatile int *>(xchg + 6) != loop + 1) {
-            const int lo = max(upper_lo - 64, upper_floor);
-            S.emit_range(lo, upper_lo - 1, 0, 1);      // one trip
-            upper_lo = lo;
-          }
-        }
-        TPAMD_ACC(12, te);
-      } else {
-        const int r = S.template add_extremal<true>(iforw_lo, pf, false, /*wait_pair=*/true);   // B inside
-        if (lane == 0) {
-          xchg[1] = r;
-          *reinterpret_cast<volatile int *>(xchg + 6) = loop + 1;
-        }
-      }
-      TPAMD_ACCC(0, t0);
-    }
-    {
-      TPAMD_T0C(t0);
-      __threadfence_block();
-      __syncthreads();               // C
-      TPAMD_ACCC(1, t0);              // time spent waiting for the partner's extremal
-    }
-    iback_lo = uniform_i32(xchg[0]);
-    iforw_hi = uniform_i32(xchg[1]);
-    if (iback_lo > icrit_lo) { status = 7; break; }
-    icrit_lo = iforw_hi;
-  }
-#endif
   TPAMD_ACCC(5, t_all);
   if (lane == 0) {
     if (w == 0) { xchg[4] = emitted_hi; xchg[5] = upper_lo; }
@@ -2404,6 +2277,7 @@ k_sweep_joint(int stride, int max_loops, JointSource src, Workspace ws, double *
   {
     // qd/qdd the loop left: from the backward wave's frontier up to the region written during
     // the first pair, or as far as the connecting forward extremal rewrote that region
+    // (measured: handing all of it to wave 1 while wave 0 runs the time sum does not shorten the step)
     const int e_hi = uniform_i32(xchg[4]), u_lo = uniform_i32(xchg[5]);
     const int f_end = uniform_i32(xchg[3]);
     S.emit_range(e_hi, min(max(u_lo - 1, f_end + 1), N - 1), w, 2);
