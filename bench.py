@@ -364,7 +364,9 @@ def main():
         torch.cuda.synchronize()
         t_begin = time.perf_counter()
         for k in range(steps):
-            E.profile_enable(2 if (with_events and k % stride == 0) else False)
+            # (the LAST step of every group of `stride`: an event pair around the very first sweep after the
+            # synchronize -- the pipeline is empty there -- costs 0.26 ms, twenty times what it costs in flight)
+            E.profile_enable(2 if (with_events and k % stride == stride - 1) else False)
             step()
         finish()                          # every batch is solved and its gather has landed on rank 0
         torch.cuda.synchronize()
@@ -373,7 +375,7 @@ def main():
         return time.perf_counter() - t_begin
 
     timing = not args.no_kernel_timing
-    stride = max(1, args.timing_stride)
+    stride = max(1, min(args.timing_stride, max(args.steps, 1)))
     # Cold figure: the same K steps right after the driver's W warm-up steps, BEFORE the clock
     # warm-up below -- what a caller sees who starts solving on an idle GPU (about 10 % slower;
     # reported next to `value` as cold_value / cold_ms_per_step).
@@ -401,8 +403,14 @@ def main():
                 go = bool(flag.item())
             if not go:
                 break
-    for _ in range(args.warmup):
+    pairs_needed = (args.steps + stride - 1) // stride
+    for i in range(args.warmup):
+        # The first event pair of a process costs about 0.25 ms once (the runtime switches the
+        # queue to timestamped dispatches) and every new pair two event creations: paid here, in
+        # the warm-up steps, not in the timed region. profile_reset() below recycles the pairs.
+        E.profile_enable(2 if (timing and i < pairs_needed) else False)
         step()
+    E.profile_enable(False)
     finish()
     torch.cuda.synchronize()
 
