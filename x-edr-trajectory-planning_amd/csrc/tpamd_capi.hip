@@ -103,6 +103,12 @@ struct tpamd_engine {
   bool order_ragged = true;    // TPAMD_ORDER_RAGGED=0: A/B the longest-first order of ragged batches
   int k1_tpb = 0;              // TPAMD_K1_TPB: threads per block of the sampling/LP kernel (A/B)
   int k1_tpb_ragged = 64;      // TPAMD_K1_TPB_RAGGED: its upper limit for ragged batches (A/B)
+  // Idle time in front of a pipelined front stage (TPAMD_FRONT_DELAY_US). The front stage of solve k+1
+  // and the sweep of solve k become runnable at the same moment (the sweep of solve k-1 has ended); if
+  // the sampling/LP kernel's 16 k blocks reach the CUs first, the sweep's workgroups (35 KB of LDS each)
+  // wait for them and the overlap is lost: 0.54 instead of 0.49 ms per step, measured with a front
+  // stage that starts 7.5 us after that moment; 10.5 us and everything above (up to 47) give the overlap.
+  int front_delay_us = 10;
   // Event timing: pending (start, stop) pairs are folded into acc_ms/acc_n and their events
   // recycled through `pool` once kMaxPendingEvents are outstanding, so a long profiled run
   // holds a bounded number of HIP events.
@@ -538,6 +544,8 @@ int tpamd_engine_create(int device_ordinal, tpamd_engine **out) {
     e->force_generic = fg && fg[0] == '1';
     const char *tr = std::getenv("TPAMD_K1_TPB_RAGGED");
     if (tr && (atoi(tr) == 64 || atoi(tr) == 128 || atoi(tr) == 256)) e->k1_tpb_ragged = atoi(tr);
+    const char *fd = std::getenv("TPAMD_FRONT_DELAY_US");
+    if (fd && std::atoi(fd) >= 0 && std::atoi(fd) <= 1000) e->front_delay_us = std::atoi(fd);
     const char *ml = std::getenv("TPAMD_LANES");
     if (ml && std::atoi(ml) >= 1 && std::atoi(ml) <= tpamd_engine::kMaxLanes) e->max_lanes = std::atoi(ml);
     const char *cf = std::getenv("TPAMD_CHAIN_FRONTS");
@@ -643,6 +651,8 @@ int solve_joint(tpamd_engine *e, const tpamd_joint_batch *bt, const tpamd_joint_
     HIPCHK(hipStreamWaitEvent(fs, e->ev_sweep[slot], 0));
   }
   const bool do_front = e->phase != 2, do_back = e->phase != 1;
+  if (do_front && piped && e->front_delay_us > 0)
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, fs, e->front_delay_us * 100);
   if (do_front) {
     Timer t(e, fs, KI_SETUP);
     hipLaunchKernelGGL(k_setup_joint, dim3((B + 127) / 128), dim3(128), 0, fs, B, N, D,

@@ -139,39 +139,68 @@ static __global__ void k_setup_joint(int B, int N, int D, double safety, const d
   if (b >= B) return;
   const int C = 2 * D;
   double *lo = ws.lim + (size_t)b * 2 * C, *hi = lo + C;
+  // every load of the thread is issued before the first use (the kernel sits at the head of the
+  // front stage's chain: its latency is part of every pipelined step); the row widths come from
+  // the registers, not from what was just stored
+  const double s0 = path_start[b], dl = delta[b], sd0 = sd_start[b], t0 = t_start[b];
+  const double sdd0 = sdd_start ? sdd_start[b] : 0.0;
+  const int Nb = path_samples(ws, b, N);
+  const bool too_many = ws.ns && ws.ns[b] > N;
   double maxw = -DBL_MAX;
   bool lower_ge_upper = false;
-  for (int d = 0; d < D; d++) {
-    const double a = amax[(size_t)b * D + d] * safety;
-    const double na = -amax[(size_t)b * D + d] * safety;
-    const double v = vmax[(size_t)b * D + d] * safety;
-    hi[d] = a;
-    lo[d] = na;
-    hi[D + d] = v * v;
-    lo[D + d] = 0.0;
+  for (int d0 = 0; d0 < D; d0 += 8) {
+    double am[8], vm[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int d = min(d0 + u, D - 1);
+      am[u] = amax[(size_t)b * D + d];
+      vm[u] = vmax[(size_t)b * D + d];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int d = d0 + u;
+      if (d < D) {
+        const double a = am[u] * safety;
+        const double na = -am[u] * safety;
+        const double v = vm[u] * safety;
+        const double vv = v * v;
+        hi[d] = a;
+        lo[d] = na;
+        hi[D + d] = vv;
+        lo[D + d] = 0.0;
+        const double wa = a - na, wv = vv - 0.0;
+        if (wa > maxw) maxw = wa;
+        if (wv > maxw) maxw = wv;
+        if (na >= a || 0.0 >= vv) lower_ge_upper = true;
+      }
+    }
   }
-  for (int c = 0; c < C; c++) {
-    const double w = hi[c] - lo[c];
-    if (w > maxw) maxw = w;
-    if (lo[c] >= hi[c]) lower_ge_upper = true;
-  }
-  const int Nb = path_samples(ws, b, N);
-  const double s0 = path_start[b];
-  const double s1 = s0 + delta[b] * (Nb - 1);
+  const double s1 = s0 + dl * (Nb - 1);
   uint32_t bits = 0;
   if (maxw <= 0) bits |= kErrInfeasible;
   if (s0 >= s1) bits |= kErrSRange;
-  if (sd_start[b] < 0) bits |= kErrSdStartNeg;
+  if (sd0 < 0) bits |= kErrSdStartNeg;
   if (lower_ge_upper) bits |= kErrLowerGeUpper;
-  if (Nb < 2 || (ws.ns && ws.ns[b] > N)) bits |= kErrTooFew;   // count outside [2, stride]
+  if (Nb < 2 || too_many) bits |= kErrTooFew;   // count outside [2, stride]
   ws.err_bits[b] = bits;
   ws.s_start[b] = s0;
   ws.s_end[b] = s1;
   ws.ds[b] = (s1 - s0) / (Nb - 1);
-  ws.sd_start[b] = sd_start[b];
-  ws.sdd_start[b] = sdd_start ? sdd_start[b] : 0.0;
-  ws.t_start[b] = t_start[b];
-  ws.delta[b] = delta[b];
+  ws.sd_start[b] = sd0;
+  ws.sdd_start[b] = sdd0;
+  ws.t_start[b] = t0;
+  ws.delta[b] = dl;
+}
+
+// One wave that does nothing for `ticks` of the 100 MHz real-time clock (front-stage delay of the
+// pipelined mode, see solve_joint).
+static __global__ void k_delay(int ticks) {
+  unsigned long long t0, t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  do {
+    __builtin_amdgcn_s_sleep(8);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  } while ((long long)(t - t0) < ticks);
 }
 
 static __global__ void k_setup_rows(int B, int N, const double *s_start, const double *s_end,
