@@ -1,3 +1,5 @@
+# Everything the round-end numbers come from, in one gpurun call (tests, rocprofv3 counter passes, bench lines,
+# other configurations, smoke):  gpurun --timeout 1200 -- "bash tools/measure_final.sh"
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r03_l_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r03_l_pytest.log
