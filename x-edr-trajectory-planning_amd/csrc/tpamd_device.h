@@ -456,33 +456,47 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
   if (b_only_from >= 0) cset.drop_lower_from(b_only_from, C);
   act.clear();
 
+  auto vel_b = [&](int c) -> double {     // B of row c >= SD: q'^2 from the register copy where there is one
+    if (SD > 0 && c < 2 * SD) { const double v = ra[c - SD]; return v * v; }
+    return r.b(c);
+  };
   // Step 2: largest feasible sd2 on the line sdd = 0.
   double sd2 = DBL_MAX, sdd = 0.0;
+  // upper edge of the screen's window, hi_lim + |hi_lim| * 1e-6 with hi_lim = sd2 + kTiny: follows sd2
+  double hi_w = (sd2 + kTiny) + fabs(sd2 + kTiny) * 1e-6;
   auto step2_row = [&](int c, double Bc) {
     if (fabs(Bc) < kTiny) return;
     if (Bc > kTiny) {
-      if (lp_cannot_pass(r.hi(c), Bc, 0.0, sd2 + kTiny)) return;
+      {   // lp_cannot_pass(hi, Bc, 0, sd2 + kTiny) with the window's upper edge kept in hi_w
+        const double ap = r.hi(c) * __builtin_amdgcn_rcp(Bc);
+        if ((ap > hi_w) || (ap < 0.0)) return;
+      }
       const double invB = 1.0 / Bc;
       const double tmp = r.hi(c) * invB;
       if (tmp < (sd2 + kTiny) && tmp > 0) {
         if (tmp < sd2 - kTiny) act.clear();
         act.set(2 * c);
         sd2 = tmp;
+        hi_w = (sd2 + kTiny) + fabs(sd2 + kTiny) * 1e-6;
       }
     } else if (Bc < -kTiny) {
-      if (lp_cannot_pass(r.lo(c), Bc, 0.0, sd2 + kTiny)) return;
+      {
+        const double ap = r.lo(c) * __builtin_amdgcn_rcp(Bc);
+        if ((ap > hi_w) || (ap < 0.0)) return;
+      }
       const double invB = 1.0 / Bc;
       const double tmp = r.lo(c) * invB;
       if (tmp < (sd2 + kTiny) && tmp > 0) {
         if (tmp < sd2 - kTiny) act.clear();
         act.set(2 * c + 1);
         sd2 = tmp;
+        hi_w = (sd2 + kTiny) + fabs(sd2 + kTiny) * 1e-6;
       }
     }
   };
   if (SD > 0) {
 #pragma unroll
-    for (int c = 0; c < SC; c++) step2_row(c, (c < SD) ? rb[c < SD ? c : 0] : r.b(c));
+    for (int c = 0; c < SC; c++) step2_row(c, (c < SD) ? rb[c < SD ? c : 0] : vel_b(c));
   } else {
     for (int c = 0; c < C; c++) step2_row(c, r.b(c));
   }
@@ -533,10 +547,15 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
 
     act.clear();
     double next_sd2 = DBL_MAX, next_sdd = 0.0;
+    // the screen's window of this pass (the margins of lp_cannot_pass, formed once; the upper edge
+    // follows next_sd2)
+    const double lo_w = sd2 - fabs(sd2) * 1e-6;
+    double up_w = (next_sd2 + kTiny) + fabs(next_sd2 + kTiny) * 1e-6;
     auto visit = [&](int s, double Ac, double Brow, double lim) {
       const double Bc = Ac * b + Brow;
       if (fabs(Bc) < kTiny) return;
-      if (lp_cannot_pass(lim - Ac * a, Bc, sd2, next_sd2 + kTiny)) return;
+      const double tmp_apx = (lim - Ac * a) * __builtin_amdgcn_rcp(Bc);
+      if ((tmp_apx > up_w) || (tmp_apx < lo_w)) return;
       const double invB = 1.0 / Bc;
       const double tmp = (lim - Ac * a) * invB;
       if (tmp < (next_sd2 + kTiny) && tmp > sd2) {
@@ -544,13 +563,14 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
         act.set(s);
         next_sd2 = tmp;
         next_sdd = a + b * next_sd2;
+        up_w = (next_sd2 + kTiny) + fabs(next_sd2 + kTiny) * 1e-6;
       }
     };
     if (SD > 0) {
 #pragma unroll
       for (int c = 0; c < SC; c++) {
         const double Ac = (c < SD) ? ra[c < SD ? c : 0] : r.a(c);
-        const double Brow = (c < SD) ? rb[c < SD ? c : 0] : r.b(c);
+        const double Brow = (c < SD) ? rb[c < SD ? c : 0] : vel_b(c);
         if (cset.has(2 * c)) visit(2 * c, Ac, Brow, r.hi(c));
         if (cset.has(2 * c + 1)) visit(2 * c + 1, Ac, Brow, r.lo(c));
       }
