@@ -464,31 +464,19 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
   double sd2 = DBL_MAX, sdd = 0.0;
   // upper edge of the screen's window, hi_lim + |hi_lim| * 1e-6 with hi_lim = sd2 + kTiny: follows sd2
   double hi_w = (sd2 + kTiny) + fabs(sd2 + kTiny) * 1e-6;
+  // (one branch per row: which bound, whether the row counts at all and the screen are folded into one
+  // condition -- divergent branches cost scalar instructions, and the scalar unit is shared by the CU)
   auto step2_row = [&](int c, double Bc) {
-    if (fabs(Bc) < kTiny) return;
-    if (Bc > kTiny) {
-      {   // lp_cannot_pass(hi, Bc, 0, sd2 + kTiny) with the window's upper edge kept in hi_w
-        const double ap = r.hi(c) * __builtin_amdgcn_rcp(Bc);
-        if ((ap > hi_w) || (ap < 0.0)) return;
-      }
+    const bool pos = Bc > kTiny, neg = Bc < -kTiny;          // (|Bc| < kTiny, NaN: neither)
+    const double lim = pos ? r.hi(c) : r.lo(c);
+    // lp_cannot_pass(lim, Bc, 0, sd2 + kTiny) with the window's upper edge kept in hi_w
+    const double ap = lim * __builtin_amdgcn_rcp(Bc);
+    if ((pos | neg) & !((ap > hi_w) | (ap < 0.0))) {
       const double invB = 1.0 / Bc;
-      const double tmp = r.hi(c) * invB;
+      const double tmp = lim * invB;
       if (tmp < (sd2 + kTiny) && tmp > 0) {
         if (tmp < sd2 - kTiny) act.clear();
-        act.set(2 * c);
-        sd2 = tmp;
-        hi_w = (sd2 + kTiny) + fabs(sd2 + kTiny) * 1e-6;
-      }
-    } else if (Bc < -kTiny) {
-      {
-        const double ap = r.lo(c) * __builtin_amdgcn_rcp(Bc);
-        if ((ap > hi_w) || (ap < 0.0)) return;
-      }
-      const double invB = 1.0 / Bc;
-      const double tmp = r.lo(c) * invB;
-      if (tmp < (sd2 + kTiny) && tmp > 0) {
-        if (tmp < sd2 - kTiny) act.clear();
-        act.set(2 * c + 1);
+        act.set(2 * c + (pos ? 0 : 1));
         sd2 = tmp;
         hi_w = (sd2 + kTiny) + fabs(sd2 + kTiny) * 1e-6;
       }
@@ -551,13 +539,14 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
     // follows next_sd2)
     const double lo_w = sd2 - fabs(sd2) * 1e-6;
     double up_w = (next_sd2 + kTiny) + fabs(next_sd2 + kTiny) * 1e-6;
-    auto visit = [&](int s, double Ac, double Brow, double lim) {
+    auto visit = [&](int s, bool member, double Ac, double Brow, double lim) {
       const double Bc = Ac * b + Brow;
-      if (fabs(Bc) < kTiny) return;
-      const double tmp_apx = (lim - Ac * a) * __builtin_amdgcn_rcp(Bc);
-      if ((tmp_apx > up_w) || (tmp_apx < lo_w)) return;
+      const double num = lim - Ac * a;
+      const double tmp_apx = num * __builtin_amdgcn_rcp(Bc);
+      // membership, the |Bc| test and the screen in one condition (one divergent branch per slot)
+      if (!(member & !(fabs(Bc) < kTiny) & !((tmp_apx > up_w) | (tmp_apx < lo_w)))) return;
       const double invB = 1.0 / Bc;
-      const double tmp = (lim - Ac * a) * invB;
+      const double tmp = num * invB;
       if (tmp < (next_sd2 + kTiny) && tmp > sd2) {
         if (tmp < next_sd2 - kTiny) act.clear();
         act.set(s);
@@ -571,13 +560,14 @@ __device__ void lp_find_max_sd2(const R &r, int C, double *sd2max, double *sddma
       for (int c = 0; c < SC; c++) {
         const double Ac = (c < SD) ? ra[c < SD ? c : 0] : r.a(c);
         const double Brow = (c < SD) ? rb[c < SD ? c : 0] : vel_b(c);
-        if (cset.has(2 * c)) visit(2 * c, Ac, Brow, r.hi(c));
-        if (cset.has(2 * c + 1)) visit(2 * c + 1, Ac, Brow, r.lo(c));
+        visit(2 * c, cset.has(2 * c), Ac, Brow, r.hi(c));
+        // (the lower-bound slots of the A = 0 rows were dropped up front and never come back)
+        if (!(b_only_from >= 0 && c >= b_only_from)) visit(2 * c + 1, cset.has(2 * c + 1), Ac, Brow, r.lo(c));
       }
     } else {
       for (int s = cset.next(0); s >= 0; s = cset.next(s + 1)) {
         const int c = s >> 1;
-        visit(s, r.a(c), r.b(c), (s & 1) ? r.lo(c) : r.hi(c));
+        visit(s, true, r.a(c), r.b(c), (s & 1) ? r.lo(c) : r.hi(c));
       }
     }
     if (!act.any()) {
