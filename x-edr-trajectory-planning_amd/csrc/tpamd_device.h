@@ -267,12 +267,15 @@ __device__ __forceinline__ void find_sdd_both_joint_screened(const double (&a)[D
                                                              const double *lim_hi, double sd2,
                                                              double *sdd_max, double *sdd_min) {
   double smax = -DBL_MAX, smin = DBL_MAX;
-  bool vel_ok = true;
+  // (no short-circuit conditions and no small if-bodies below: every divergent branch costs scalar
+  // instructions of a unit the whole CU shares -- selects instead)
+  bool vel_bad = false;
 #pragma unroll
   for (int j = 0; j < D; j++) {
     const double v = (a[j] * a[j]) * sd2;
-    if (v + kTiny < 0.0 || v - kTiny > lim_hi[D + j]) vel_ok = false;
+    vel_bad = vel_bad | (v + kTiny < 0.0) | (v - kTiny > lim_hi[D + j]);
   }
+  const bool vel_ok = !vel_bad;
   if (vel_ok) {
     double bs[D], hi[D], c_lo[D], c_hi[D];
     double Lmax = -DBL_MAX, Umin = DBL_MAX;
@@ -283,25 +286,23 @@ __device__ __forceinline__ void find_sdd_both_joint_screened(const double (&a)[D
       const double r = __builtin_amdgcn_rcp(a[j]);
       c_lo[j] = (-hi[j] - bs[j]) * r;          // estimate of the candidate on the lower bound
       c_hi[j] = (hi[j] - bs[j]) * r;           // ... on the upper bound
-      if (!is_tiny(a[j])) {
-        const double pad = kTiny * fabs(r);
-        const double l = fmin(c_lo[j], c_hi[j]) - pad, u = fmax(c_lo[j], c_hi[j]) + pad;
-        // NaN ends (overflowing estimates) leave the intersection unchanged: never screens
-        if (l > Lmax) Lmax = l;
-        if (u < Umin) Umin = u;
-      }
+      const bool counts = !is_tiny(a[j]);
+      const double pad = kTiny * fabs(r);
+      const double l = fmin(c_lo[j], c_hi[j]) - pad, u = fmax(c_lo[j], c_hi[j]) + pad;
+      // NaN ends (overflowing estimates) leave the intersection unchanged: never screens
+      Lmax = (counts & (l > Lmax)) ? l : Lmax;
+      Umin = (counts & (u < Umin)) ? u : Umin;
     }
     unsigned survivors = 0;
 #pragma unroll
     for (int i = 0; i < D; i++) {
-      if (!is_tiny(a[i])) {
+      const bool counts = !is_tiny(a[i]);
 #pragma unroll
-        for (int w = 0; w < 2; w++) {
-          const double c = w ? c_hi[i] : c_lo[i];
-          const double mg = 1e-6 * (fabs(Lmax) + fabs(Umin) + fabs(c)) + 1e-290;
-          const bool out = (c < Lmax - mg) || (c > Umin + mg);
-          if (!out) survivors |= 1u << (2 * i + w);
-        }
+      for (int w = 0; w < 2; w++) {
+        const double c = w ? c_hi[i] : c_lo[i];
+        const double mg = 1e-6 * (fabs(Lmax) + fabs(Umin) + fabs(c)) + 1e-290;
+        const bool out = (c < Lmax - mg) | (c > Umin + mg);
+        survivors |= (counts & !out) ? (1u << (2 * i + w)) : 0u;
       }
     }
     while (__any(survivors != 0u)) {
@@ -426,15 +427,14 @@ __device__ __forceinline__ bool lp_pair_optimal(const R &r, int s1, int s2) {
   const bool first_upper = !(s1 & 1), second_upper = !(s2 & 1);
   const double a1 = r.a(first), a2 = r.a(second);
   const double denom = a2 * r.b(first) - a1 * r.b(second);
-  if (fabs(denom) < kTiny) return false;
   const double t1 = denom * a1;
   const double t2 = denom * (-a2);
-  if (first_upper) {
-    if (second_upper) return t1 <= 0 && t2 <= 0;
-    return t1 >= 0 && t2 <= 0;
-  }
-  if (second_upper) return t1 <= 0 && t2 >= 0;
-  return t1 >= 0 && t2 >= 0;
+  // (.cc:1105-1147 as one expression: first_upper ? (second_upper ? t1 <= 0 && t2 <= 0 : t1 >= 0 && t2 <= 0)
+  //  : (second_upper ? t1 <= 0 && t2 >= 0 : t1 >= 0 && t2 >= 0), false for |denom| < kTiny)
+  // -- the sign asked of t1 follows the SECOND slot's bound, that of t2 the FIRST slot's
+  const bool c1 = second_upper ? (t1 <= 0) : (t1 >= 0);
+  const bool c2 = first_upper ? (t2 <= 0) : (t2 >= 0);
+  return !(fabs(denom) < kTiny) & c1 & c2;
 }
 
 // SD > 0 (with SC = number of rows): the first SD rows' A and B are also available in the
