@@ -297,3 +297,31 @@ def test_config3_full_size_properties(env):
     torch.cuda.synchronize()
     for k in ("time", "sd", "sdd", "qd", "qdd", "status"):
         assert torch.equal(again[k], out[k]), k
+
+
+@pytest.mark.parametrize("delay_us", ["0", "3", "60"])
+def test_front_stage_delay_changes_no_result(env, monkeypatch, delay_us):
+    """TPAMD_FRONT_DELAY_US (the idle kernel in front of a pipelined front stage, DESIGN.md section 4:
+    it decides whether the overlap happens, never what is computed): pipelined solves of two alternating
+    batches with no, a short and a long delay reproduce the unpipelined engine bit for bit."""
+    torch, eng, syn = env["torch"], env["eng"], env["syn"]
+    B, D, N = 256, 7, 1200
+    batches = [syn.make_joint_batch(B, D, N, first_path_index=f) for f in (0, 3000)]
+    inps = [eng.upload_joint_batch(b, env["dev"]) for b in batches]
+    refs = []
+    for inp in inps:
+        ref = eng.alloc_joint_outputs(B, N, D, env["dev"])
+        env["E"].time_joint_paths(inp, ref, N)
+        refs.append(ref)
+    monkeypatch.setenv("TPAMD_FRONT_DELAY_US", delay_us)
+    E2 = eng.Engine(0)
+    E2.set_pipelining(1)
+    outs = [eng.alloc_joint_outputs(B, N, D, env["dev"]) for _ in range(2)]
+    torch.cuda.synchronize()
+    for it in range(12):
+        E2.time_joint_paths(inps[it % 2], outs[it % 2], N)
+    torch.cuda.synchronize()
+    for out, ref in zip(outs, refs):
+        for k in KEYS + ("status", "last_extremal_index"):
+            assert torch.equal(out[k], ref[k]), (delay_us, k)
+    E2.close()
