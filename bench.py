@@ -53,11 +53,13 @@ def algorithmic_bytes_per_path(D, N, P):
 
 
 def gather_bytes_per_path(mode, D, N):
-    """Bytes one path contributes to the gather payload. compact: (sd, sdd) and the scalars
-    (ds, time_start) -- the root rebuilds t from sd (and s = s_start + i*ds, an arithmetic
-    sequence); profile: (t, sd, sdd); full: q as well."""
+    """Bytes one path contributes to the gather payload. minimal: sd and the scalars (ds,
+    time_start) -- the root rebuilds t from sd (and s = s_start + i*ds, an arithmetic sequence);
+    compact: sdd as well; profile: (t, sd, sdd); full: q as well."""
     if mode == "none":
         return 0
+    if mode == "minimal":
+        return 8 * N + 16
     if mode == "compact":
         return 8 * N * 2 + 16
     return 8 * N * 3 + (8 * N * D if mode == "full" else 0)
@@ -203,11 +205,12 @@ def main():
     ap.add_argument("--paths-per-gpu", type=int, default=0, help="override the workload's batch")
     ap.add_argument("--dofs", type=int, default=7)
     ap.add_argument("--samples", type=int, default=2000)
-    ap.add_argument("--gather", choices=("compact", "profile", "full"), default="compact",
-                    help="multi-GPU payload: compact = (sd, sdd) + two scalars per path, the root "
-                         "rebuilds t from sd with the solver's own operations inside the timed region "
-                         "(32 KB per path through the root's xGMI links instead of 48); profile = "
-                         "(t, sd, sdd); full = q as well")
+    ap.add_argument("--gather", choices=("minimal", "compact", "profile", "full"), default="minimal",
+                    help="multi-GPU payload: minimal = sd + two scalars per path, the root rebuilds t "
+                         "from sd with the solver's own operations inside the timed region and s from ds "
+                         "(16 KB per path through the root's xGMI links: of north_star's t, s, sd, q "
+                         "everything but q); compact = sdd as well (32 KB); profile = (t, sd, sdd), 48 KB; "
+                         "full = q as well, 160 KB")
     ap.add_argument("--pipeline", type=int, choices=(0, 1, 2), default=1,
                     help="engine pipelining across steps (tpamd_engine_set_pipelining): 0 one kernel "
                          "at a time; 1 (default) the sampling/LP kernel of step k+1 runs under the sweep of "
@@ -281,7 +284,8 @@ def main():
     # time_optimal_path_timing.cc:540-547, which the root rebuilds from per-path scalars.)
     # Two buffers, so that the gather of batch k (rank 0's inbound xGMI links) overlaps the solve
     # of batch k+1.
-    compact = args.gather == "compact"
+    compact = args.gather in ("compact", "minimal")     # t is rebuilt on the root
+    with_sdd = args.gather == "compact"                 # sdd is part of the payload
     shared = eng.alloc_joint_outputs(B, N, D, dev, with_q=(args.gather != "full"))
     # mode 2 lets the sweeps of steps k and k+1 overlap: every output array then exists once per
     # slot (in the other modes the sweeps run in order on one stream and the arrays that are not
@@ -290,15 +294,16 @@ def main():
                 else shared]
     outs = []
     if compact:
-        # flat payload per rank: sd [B][N] | sdd [B][N] | ds [B] | time_start [B]
-        flat = 2 * B * N + 2 * B
+        # flat payload per rank: sd [B][N] | (compact: sdd [B][N] |) ds [B] | time_start [B]
+        off_ds = (2 if with_sdd else 1) * B * N
+        flat = off_ds + 2 * B
         root_time = None
 
         def rebuild(slot):
             # on the root, right after the gather of this slot has landed: t of every shard's
             # paths from its sd, ds and time_start (own shard included: one launch)
             r0 = G.recv[slot]
-            E.rebuild_time(r0[0, :B * N], r0[0, 2 * B * N:2 * B * N + B], r0[0, 2 * B * N + B:],
+            E.rebuild_time(r0[0, :B * N], r0[0, off_ds:off_ds + B], r0[0, off_ds + B:],
                            root_time[slot], world, B, N, flat)
 
         G = shd.PipelinedGather((flat,), torch.float64, dev, depth=2,
@@ -317,9 +322,11 @@ def main():
         for slot in range(2):
             o = dict(per_slot[slot])
             p = G.send[slot]
-            o["sd"], o["sdd"] = p[:B * N].view(B, N), p[B * N:2 * B * N].view(B, N)
-            p[2 * B * N:2 * B * N + B].copy_(ds_t)
-            p[2 * B * N + B:].copy_(t0_t)
+            o["sd"] = p[:B * N].view(B, N)
+            if with_sdd:
+                o["sdd"] = p[B * N:2 * B * N].view(B, N)      # (minimal: sdd stays in the solve's own buffer)
+            p[off_ds:off_ds + B].copy_(ds_t)
+            p[off_ds + B:].copy_(t0_t)
             outs.append(o)
     else:
         rows = 3 + (D if args.gather == "full" else 0)
@@ -505,7 +512,9 @@ def main():
                                   # what reaches rank 0, against north_star's "t, s, s', q": q is part of
                                   # the payload only with --gather full (link-bound at about 4x on 8 GPUs)
                                   "named_outputs_at_root": (None if not distributed else
-                                                            {"compact": ["sd", "sdd", "t (rebuilt on the root from sd)",
+                                                            {"minimal": ["sd", "t (rebuilt on the root from sd)",
+                                                                         "s (arithmetic sequence from ds)"],
+                                                             "compact": ["sd", "sdd", "t (rebuilt on the root from sd)",
                                                                          "s (arithmetic sequence from ds)"],
                                                              "profile": ["t", "sd", "sdd", "s (arithmetic sequence from ds)"],
                                                              "full": ["t", "sd", "sdd", "q", "s (arithmetic sequence from ds)"]}
@@ -514,10 +523,10 @@ def main():
                                   "rebuilt_time_equals_local_solve": rebuilt_ok,
                                   "bytes_into_rank0_per_step": gb * B * (world - 1),
                                   "what": (("ONE RCCL gather per step of the packed payload "
-                                            "(sd, sdd and the scalars ds, time_start per path; the root "
+                                            "(sd" + (", sdd" if with_sdd else "") + " and the scalars ds, time_start per path; the root "
                                             "rebuilds t from sd with the solver's operations -- "
                                             "tpamd_rebuild_time_device, inside the timed region -- and s = "
-                                            "s_start + i*ds is an arithmetic sequence; q, qd, qdd stay on the "
+                                            "s_start + i*ds is an arithmetic sequence; " + ("" if with_sdd else "sdd, ") + "q, qd, qdd stay on the "
                                             "producing GPU) to rank 0, overlapped with the next step's solve "
                                             "(double-buffered), all inside the timed region") if compact else
                                            ("ONE RCCL gather per step of the packed payload "

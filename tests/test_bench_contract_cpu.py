@@ -39,6 +39,7 @@ def test_bench_refuses_to_run_without_a_gpu():
 def test_gather_payload_bytes_and_counter_file_binding(tmp_path, monkeypatch):
     bench = _bench()
     assert bench.gather_bytes_per_path("none", 7, 2000) == 0
+    assert bench.gather_bytes_per_path("minimal", 7, 2000) == 16016       # sd, ds, time_start (default)
     assert bench.gather_bytes_per_path("compact", 7, 2000) == 32016       # sd, sdd, ds, time_start
     assert bench.gather_bytes_per_path("profile", 7, 2000) == 48000       # t, sd, sdd
     assert bench.gather_bytes_per_path("full", 7, 2000) == 160000         # + q
